@@ -1,0 +1,101 @@
+"""ctypes binding of libchiron_amd.so (include/chiron_amd.h).
+
+The library is the product: there is no Python or CPU fallback.  Importing
+this module never touches the GPU; `load()` raises if the shared object has
+not been built (python -c "import __graft_entry__ as g; g.build()").
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libchiron_amd.so")
+
+MAX_BLOCKS = 8
+CLASSES = 5
+
+OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
+RNN_STACK, RNN_MULTI = 0, 1
+BN_POPULATION, BN_BATCH = 0, 1
+F32, F16 = 0, 1
+X_ON_DEVICE, WANT_PROB, WANT_LOGITS, NO_DECODE_COPY = 1, 2, 4, 8
+KERNAL_GLUE, KERNAL_STICK = 1, 2
+
+
+class ResBlock(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("k", C.c_int32),
+                ("stride", C.c_int32), ("i_bn", C.c_int32)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("blocks", ResBlock * MAX_BLOCKS), ("rnn_kind", C.c_int32),
+                ("rnn_layers", C.c_int32), ("hidden", C.c_int32), ("classes", C.c_int32),
+                ("bn_mode", C.c_int32)]
+
+
+class EngineOpts(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("max_batch", C.c_int32), ("segment_len", C.c_int32),
+                ("n_slots", C.c_int32), ("dtype", C.c_int32), ("max_beam", C.c_int32)]
+
+
+class Decoded(C.Structure):
+    _fields_ = [("nnz", C.c_int64), ("indices", C.POINTER(C.c_int64)), ("values", C.POINTER(C.c_int64)),
+                ("dense_shape", C.c_int64 * 2), ("log_prob", C.POINTER(C.c_float)),
+                ("prob_logits", C.POINTER(C.c_float)), ("logits", C.POINTER(C.c_float)),
+                ("batch", C.c_int32), ("T", C.c_int32)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("total_ms", C.c_double), ("launches", C.c_int64),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+# every symbol include/chiron_amd.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("chiron_weights_size", C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)]),
+    ("chiron_engine_create", C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_size_t, C.POINTER(EngineOpts),
+                                       C.POINTER(C.c_void_p)]),
+    ("chiron_engine_destroy", None, [C.c_void_p]),
+    ("chiron_engine_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    ("chiron_engine_submit", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_uint32]),
+    ("chiron_engine_collect", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Decoded)]),
+    ("chiron_engine_sync", C.c_int, [C.c_void_p]),
+    ("chiron_engine_device_results", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("chiron_engine_profile", C.c_int, [C.c_void_p, C.c_int32]),
+    ("chiron_engine_profile_read", C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
+    ("chiron_assemble", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.POINTER(C.c_int64)]),
+    ("chiron_last_error", C.c_char_p, []),
+    ("chiron_abi_version", C.c_int32, []),
+]
+
+_lib = None
+
+
+class ChironError(RuntimeError):
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, "libchiron_amd status %d: %s" % (status, message))
+        self.status = status
+
+
+def load():
+    """Load the HIP library.  Fails loudly when it is missing: no fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). chiron_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OK:
+        raise ChironError(status, load().chiron_last_error().decode("utf-8", "replace"))

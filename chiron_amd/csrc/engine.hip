@@ -1,0 +1,892 @@
+// libchiron_amd.so -- engine: C ABI (include/chiron_amd.h), weight preparation, workspace, and the
+// launch sequence that replaces chiron_model.inference (chiron_model.py:134-172) + the decode
+// sub-graph (chiron_eval.py:465-492) of the reference.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/chiron_amd.h"
+#include "kernels.h"
+
+using namespace chiron;
+
+// ----------------------------------------------------------------------------------------------
+// error plumbing: never throw across the ABI
+// ----------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static chiron_status fail(chiron_status st, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return st;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(CHIRON_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                                       \
+  } while (0)
+
+namespace chiron {
+chiron_status set_error(chiron_status st, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return st;
+}
+}  // namespace chiron
+
+extern "C" const char* chiron_last_error(void) { return g_err; }
+extern "C" int32_t chiron_abi_version(void) { return CHIRON_ABI_VERSION; }
+
+static int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+// TF 'SAME' padding: out = ceil(W/s), pad_total = max((out-1)s + k - W, 0), left = total/2
+static void same_pad(int w, int k, int s, int* out, int* left) {
+  *out = (w + s - 1) / s;
+  int tot = (*out - 1) * s + k - w;
+  if (tot < 0) tot = 0;
+  *left = tot / 2;
+}
+
+// ----------------------------------------------------------------------------------------------
+// model description helpers
+// ----------------------------------------------------------------------------------------------
+static chiron_status validate_desc(const chiron_model_desc* d) {
+  if (!d) return fail(CHIRON_ERR_INVALID, "null model descriptor");
+  if (d->n_blocks < 1 || d->n_blocks > CHIRON_MAX_BLOCKS) return fail(CHIRON_ERR_INVALID, "n_blocks %d out of range", d->n_blocks);
+  for (int i = 0; i < d->n_blocks; ++i) {
+    const chiron_res_block& b = d->blocks[i];
+    const int want_in = i == 0 ? 1 : d->blocks[i - 1].out_channels;
+    if (b.in_channels != want_in) return fail(CHIRON_ERR_INVALID, "block %d: in_channels %d, expected %d", i, b.in_channels, want_in);
+    if (b.out_channels < 4 || b.out_channels % 4) return fail(CHIRON_ERR_INVALID, "block %d: out_channels must be a multiple of 4", i);
+    if (b.k < 1 || b.k > GEMM_MAX_SEG) return fail(CHIRON_ERR_INVALID, "block %d: conv2b width %d unsupported (1..%d)", i, b.k, GEMM_MAX_SEG);
+    if (b.stride < 1) return fail(CHIRON_ERR_INVALID, "block %d: stride %d", i, b.stride);
+  }
+  if (d->rnn_kind != CHIRON_RNN_STACK && d->rnn_kind != CHIRON_RNN_MULTI) return fail(CHIRON_ERR_INVALID, "rnn_kind %d", d->rnn_kind);
+  if (d->rnn_layers < 1 || d->rnn_layers > 8) return fail(CHIRON_ERR_INVALID, "rnn_layers %d unsupported (1..8)", d->rnn_layers);
+  if (d->hidden < 4 || d->hidden > 100 || d->hidden % 4) return fail(CHIRON_ERR_INVALID, "hidden %d unsupported (multiple of 4, <= 100)", d->hidden);
+  if (d->classes < 2 || d->classes > CHIRON_KMAX) return fail(CHIRON_ERR_INVALID, "classes %d unsupported (2..%d)", d->classes, CHIRON_KMAX);
+  if (d->bn_mode != CHIRON_BN_POPULATION && d->bn_mode != CHIRON_BN_BATCH) return fail(CHIRON_ERR_INVALID, "bn_mode %d", d->bn_mode);
+  return CHIRON_OK;
+}
+
+static int lstm_in_width(const chiron_model_desc* d, int layer) {
+  if (layer == 0) return d->blocks[d->n_blocks - 1].out_channels;
+  return d->rnn_kind == CHIRON_RNN_STACK ? 2 * d->hidden : d->hidden;
+}
+
+extern "C" chiron_status chiron_weights_size(const chiron_model_desc* d, size_t* n_floats) {
+  chiron_status st = validate_desc(d);
+  if (st) return st;
+  if (!n_floats) return fail(CHIRON_ERR_INVALID, "null n_floats");
+  size_t n = 0;
+  for (int i = 0; i < d->n_blocks; ++i) {
+    const chiron_res_block& b = d->blocks[i];
+    const size_t ci = b.in_channels, co = b.out_channels;
+    n += ci * co + (b.i_bn ? 4 * co : 0);  // branch1
+    n += ci * co + 4 * co;                 // conv2a
+    n += (size_t)b.k * co * co + 4 * co;   // conv2b
+    n += co * co + 4 * co;                 // conv2c
+  }
+  const size_t H = d->hidden;
+  for (int l = 0; l < d->rnn_layers; ++l) n += 2 * ((lstm_in_width(d, l) + H) * 4 * H + 4 * H);
+  n += 2 * H + H + H * d->classes + d->classes;
+  *n_floats = n;
+  return CHIRON_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// engine state
+// ----------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct ConvGemmPlan {
+  // device weights for one fused GEMM
+  float* Wt = nullptr;
+  float* shift = nullptr;
+  int N = 0, Npad = 0, K = 0;
+};
+
+struct BlockPlan {
+  bool lift = false;
+  int c_in = 0, c = 0, k = 0, stride = 1, left = 0;
+  int t_in = 0, t_out = 0;
+  float *lift_a = nullptr, *lift_b = nullptr;  // lift: conv2a folded scale/shift
+  float* res_a = nullptr;                      // lift: branch1 folded scale
+  ConvGemmPlan ga, gb, gc;                     // conv2a (non-lift), conv2b, conv2c(+conv1)
+};
+
+struct LstmPlan {
+  int in_w = 0;
+  ConvGemmPlan proj[2];  // STACK / layer 0: proj[0] covers both directions; MULTI l>0: one per dir
+  int nproj = 1;
+  float* wfrag = nullptr;
+};
+
+struct ProfEvent {
+  int name_id;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  float* sig = nullptr;
+  int32_t* seq = nullptr;
+  float* act[3] = {nullptr, nullptr, nullptr};
+  float* z = nullptr;
+  float* lasth[2] = {nullptr, nullptr};
+  float* logits = nullptr;
+  uint8_t* labels = nullptr;
+  int32_t* count = nullptr;
+  float* log_prob = nullptr;
+  float* prob = nullptr;
+  int64_t* offsets = nullptr;
+  int64_t* indices = nullptr;
+  int64_t* values = nullptr;
+  int64_t* meta = nullptr;
+  void* beam_ws = nullptr;
+  size_t beam_ws_bytes = 0;
+  // pinned host
+  float* h_sig = nullptr;
+  int32_t* h_seq = nullptr;
+  int64_t* h_indices = nullptr;
+  int64_t* h_values = nullptr;
+  int64_t* h_meta = nullptr;
+  float* h_log_prob = nullptr;
+  float* h_prob = nullptr;
+  float* h_logits = nullptr;
+  // state of the in-flight batch
+  bool busy = false;
+  int batch = 0;
+  uint32_t flags = 0;
+  const float* sig_used = nullptr;
+  std::vector<ProfEvent> events;
+};
+
+struct chiron_engine {
+  chiron_model_desc desc;
+  chiron_engine_opts opts;
+  int L = 0, T = 0, C = 0, H = 0, K = 0;
+  int maxB = 0, BP = 0;
+  int hpz = 0, tiles = 0;
+  std::vector<BlockPlan> blocks;
+  std::vector<LstmPlan> lstm;
+  float *fc_w = nullptr, *fc_b = nullptr, *fc_wc = nullptr, *fc_bc = nullptr;
+  std::vector<Slot> slots;
+  std::vector<void*> owned;  // device allocations freed on destroy
+  bool profiling = false;
+  std::vector<std::string> prof_names;
+  std::mutex mu;
+};
+
+static chiron_status dev_alloc(chiron_engine* e, void** p, size_t bytes, bool zero) {
+  HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+  e->owned.push_back(*p);
+  if (zero) HIP_TRY(hipMemset(*p, 0, bytes ? bytes : 16));
+  return CHIRON_OK;
+}
+template <typename Tp>
+static chiron_status dev_upload(chiron_engine* e, Tp** p, const std::vector<Tp>& h) {
+  chiron_status st = dev_alloc(e, (void**)p, h.size() * sizeof(Tp), false);
+  if (st) return st;
+  HIP_TRY(hipMemcpy(*p, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
+  return CHIRON_OK;
+}
+
+// folded BN (cnn.py:125-163 population branch; association order of the .meta graph):
+//   inv = rsqrt(var + 1e-5) * scale ; y = x*inv + (offset - mean*inv)
+struct BnFold {
+  std::vector<float> inv, sh;
+};
+static BnFold fold_bn(const float* scale, const float* offset, const float* mean, const float* var, int n) {
+  BnFold f;
+  f.inv.resize(n);
+  f.sh.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const float inv = (1.0f / sqrtf(var[i] + 1e-5f)) * scale[i];
+    f.inv[i] = inv;
+    f.sh[i] = offset[i] - mean[i] * inv;
+  }
+  return f;
+}
+
+static chiron_status upload_gemm(chiron_engine* e, ConvGemmPlan* g, const std::vector<float>& Wt, const std::vector<float>& shift, int N, int Npad, int K) {
+  g->N = N;
+  g->Npad = Npad;
+  g->K = K;
+  chiron_status st = dev_upload(e, &g->Wt, Wt);
+  if (st) return st;
+  return dev_upload(e, &g->shift, shift);
+}
+
+static chiron_status build_plans(chiron_engine* e, const float* w) {
+  const chiron_model_desc& d = e->desc;
+  if (d.bn_mode != CHIRON_BN_POPULATION)
+    return fail(CHIRON_ERR_INVALID, "bn_mode=batch (HEAD simple_global_bn) is not implemented in this build; "
+                                    "the shipped checkpoints use population statistics");
+  int t = e->L;
+  const float* p = w;
+  for (int bi = 0; bi < d.n_blocks; ++bi) {
+    const chiron_res_block& b = d.blocks[bi];
+    BlockPlan bp;
+    bp.lift = b.in_channels == 1;
+    bp.c_in = b.in_channels;
+    bp.c = b.out_channels;
+    bp.k = b.k;
+    bp.stride = b.stride;
+    bp.t_in = t;
+    same_pad(t, b.k, b.stride, &bp.t_out, &bp.left);
+    const int ci = b.in_channels, co = b.out_channels;
+    const float* W1 = p;
+    p += (size_t)ci * co;
+    BnFold f1;
+    if (b.i_bn) {
+      f1 = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
+      p += 4 * co;
+    } else {
+      f1.inv.assign(co, 1.0f);
+      f1.sh.assign(co, 0.0f);
+    }
+    const float* W2a = p;
+    p += (size_t)ci * co;
+    BnFold f2a = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
+    p += 4 * co;
+    const float* W2b = p;
+    p += (size_t)b.k * co * co;
+    BnFold f2b = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
+    p += 4 * co;
+    const float* W2c = p;
+    p += (size_t)co * co;
+    BnFold f2c = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
+    p += 4 * co;
+
+    const int Npad = roundup(co, GEMM_BN);
+    const int cop = roundup(co, GEMM_BK);
+    chiron_status st;
+    // conv2b: Wt[n][tap*cop + c] = W2b[tap][c][n] * inv2b[n]
+    {
+      const int K = b.k * cop;
+      std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
+      for (int n = 0; n < co; ++n) {
+        for (int tap = 0; tap < b.k; ++tap)
+          for (int c = 0; c < co; ++c) Wt[(size_t)n * K + tap * cop + c] = W2b[((size_t)tap * co + c) * co + n] * f2b.inv[n];
+        sh[n] = f2b.sh[n];
+      }
+      if ((st = upload_gemm(e, &bp.gb, Wt, sh, co, Npad, K))) return st;
+    }
+    if (bp.lift) {
+      std::vector<float> la(cop, 0.f), lb(cop, 0.f), ra(Npad, 0.f);
+      for (int c = 0; c < co; ++c) {
+        la[c] = W2a[c] * f2a.inv[c];
+        lb[c] = f2a.sh[c];
+        ra[c] = W1[c] * f1.inv[c];
+      }
+      if ((st = dev_upload(e, &bp.lift_a, la))) return st;
+      if ((st = dev_upload(e, &bp.lift_b, lb))) return st;
+      if ((st = dev_upload(e, &bp.res_a, ra))) return st;
+      // conv2c with the branch1 shift folded into the epilogue shift
+      const int K = cop;
+      std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
+      for (int n = 0; n < co; ++n) {
+        for (int c = 0; c < co; ++c) Wt[(size_t)n * K + c] = W2c[(size_t)c * co + n] * f2c.inv[n];
+        sh[n] = f2c.sh[n] + f1.sh[n];
+      }
+      if ((st = upload_gemm(e, &bp.gc, Wt, sh, co, Npad, K))) return st;
+    } else {
+      const int cip = roundup(ci, GEMM_BK);
+      {
+        const int K = cip;
+        std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
+        for (int n = 0; n < co; ++n) {
+          for (int c = 0; c < ci; ++c) Wt[(size_t)n * K + c] = W2a[(size_t)c * co + n] * f2a.inv[n];
+          sh[n] = f2a.sh[n];
+        }
+        if ((st = upload_gemm(e, &bp.ga, Wt, sh, co, Npad, K))) return st;
+      }
+      {
+        // conv2c and branch1/conv1 fused along K: [conv2b output | block input]
+        const int K = cop + cip;
+        std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
+        for (int n = 0; n < co; ++n) {
+          for (int c = 0; c < co; ++c) Wt[(size_t)n * K + c] = W2c[(size_t)c * co + n] * f2c.inv[n];
+          for (int c = 0; c < ci; ++c) Wt[(size_t)n * K + cop + c] = W1[(size_t)c * co + n] * f1.inv[n];
+          sh[n] = f2c.sh[n] + f1.sh[n];
+        }
+        if ((st = upload_gemm(e, &bp.gc, Wt, sh, co, Npad, K))) return st;
+      }
+    }
+    e->blocks.push_back(bp);
+    t = bp.t_out;
+  }
+  e->T = t;
+  e->C = d.blocks[d.n_blocks - 1].out_channels;
+
+  // ---- LSTM layers
+  const int H = d.hidden;
+  e->hpz = roundup(H, 16);
+  e->tiles = 4 * (e->hpz / 16);
+  const int zc = e->tiles * 16;  // z columns per direction
+  const int KS = lstm_ksteps(100);  // the recurrence kernel is instantiated for 25 k-steps
+  for (int l = 0; l < d.rnn_layers; ++l) {
+    LstmPlan lp;
+    lp.in_w = lstm_in_width(&d, l);
+    const float* kern[2];
+    const float* bias[2];
+    for (int dir = 0; dir < 2; ++dir) {
+      kern[dir] = p;
+      p += (size_t)(lp.in_w + H) * 4 * H;
+      bias[dir] = p;
+      p += 4 * H;
+    }
+    const bool split = d.rnn_kind == CHIRON_RNN_MULTI && l > 0;
+    lp.nproj = split ? 2 : 1;
+    const int Kp = roundup(lp.in_w, GEMM_BK);
+    chiron_status st;
+    for (int pj = 0; pj < lp.nproj; ++pj) {
+      const int ndir = split ? 1 : 2;
+      const int N = ndir * zc;
+      const int Npad = roundup(N, GEMM_BN);
+      std::vector<float> Wt((size_t)Npad * Kp, 0.f), sh(Npad, 0.f);
+      for (int n = 0; n < N; ++n) {
+        const int dir = split ? pj : n / zc;
+        const int nl = n % zc;
+        const int g = nl / e->hpz, unit = nl % e->hpz;
+        if (unit >= H) continue;
+        for (int k = 0; k < lp.in_w; ++k) Wt[(size_t)n * Kp + k] = kern[dir][(size_t)k * 4 * H + g * H + unit];
+        // forget_bias = 1.0 (TF LSTMCell default; Add(+1.0) const in the .meta while-body) folded here
+        sh[n] = bias[dir][g * H + unit] + (g == 2 ? 1.0f : 0.0f);
+      }
+      if ((st = upload_gemm(e, &lp.proj[pj], Wt, sh, N, Npad, Kp))) return st;
+    }
+    // recurrent weights in MFMA B-fragment order: [dir][wave][ti = ubl*4 + g][s][lane]
+    std::vector<float> wf((size_t)2 * LSTM_WAVES * 8 * KS * 64, 0.f);
+    for (int dir = 0; dir < 2; ++dir)
+      for (int wv = 0; wv < LSTM_WAVES; ++wv)
+        for (int ubl = 0; ubl < 2; ++ubl)
+          for (int g = 0; g < 4; ++g)
+            for (int s = 0; s < KS; ++s)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int k = 4 * s + (lane >> 4);
+                const int unit = (wv * 2 + ubl) * 16 + (lane & 15);
+                float v = 0.f;
+                if (k < H && unit < H) v = kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + unit];
+                wf[((((size_t)dir * LSTM_WAVES + wv) * 8 + ubl * 4 + g) * KS + s) * 64 + lane] = v;
+              }
+    if ((st = dev_upload(e, &lp.wfrag, wf))) return st;
+    e->lstm.push_back(lp);
+  }
+  // ---- FC head (raw)
+  {
+    chiron_status st;
+    std::vector<float> a(p, p + 2 * H);
+    p += 2 * H;
+    std::vector<float> b(p, p + H);
+    p += H;
+    std::vector<float> c(p, p + (size_t)H * d.classes);
+    p += (size_t)H * d.classes;
+    std::vector<float> dd(p, p + d.classes);
+    p += d.classes;
+    if ((st = dev_upload(e, &e->fc_w, a))) return st;
+    if ((st = dev_upload(e, &e->fc_b, b))) return st;
+    if ((st = dev_upload(e, &e->fc_wc, c))) return st;
+    if ((st = dev_upload(e, &e->fc_bc, dd))) return st;
+  }
+  return CHIRON_OK;
+}
+
+static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  const size_t B = e->maxB, BP = e->BP, L = e->L, T = e->T, H = e->H, K = e->K;
+  size_t tmax = 0, cmax = 0;
+  for (const BlockPlan& b : e->blocks) {
+    if (!b.lift) tmax = std::max<size_t>(tmax, b.t_in);
+    tmax = std::max<size_t>(tmax, b.t_out);
+    cmax = std::max<size_t>(cmax, b.c);
+  }
+  chiron_status st;
+  if ((st = dev_alloc(e, (void**)&s->sig, B * L * 4, true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->seq, BP * 4, true))) return st;
+  for (int i = 0; i < 3; ++i)
+    if ((st = dev_alloc(e, (void**)&s->act[i], B * tmax * cmax * 4, false))) return st;
+  if ((st = dev_alloc(e, (void**)&s->z, T * (BP / 16) * 2 * e->tiles * 256 * 4, true))) return st;
+  for (int i = 0; i < 2; ++i)
+    if ((st = dev_alloc(e, (void**)&s->lasth[i], T * BP * 2 * H * 4, true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->logits, B * T * K * 4, false))) return st;
+  if ((st = dev_alloc(e, (void**)&s->labels, B * T, false))) return st;
+  if ((st = dev_alloc(e, (void**)&s->count, B * 4, true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->log_prob, B * 4, true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->prob, B * 4, true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->offsets, (B + 1) * 8, true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->indices, B * T * 16, false))) return st;
+  if ((st = dev_alloc(e, (void**)&s->values, B * T * 8, false))) return st;
+  if ((st = dev_alloc(e, (void**)&s->meta, 3 * 8, true))) return st;
+  if (e->opts.max_beam > 0) {
+    s->beam_ws_bytes = beam_workspace_bytes((int)B, (int)T, e->opts.max_beam);
+    if ((st = dev_alloc(e, &s->beam_ws, s->beam_ws_bytes, false))) return st;
+  }
+  HIP_TRY(hipHostMalloc((void**)&s->h_sig, B * L * 4, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_seq, BP * 4, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_indices, B * T * 16, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_values, B * T * 8, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_meta, 3 * 8, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_log_prob, B * 4, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_prob, B * 4, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_logits, B * T * K * 4, hipHostMallocDefault));
+  memset(s->h_prob, 0, B * 4);
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, const float* weights, size_t n_floats,
+                                              const chiron_engine_opts* opts, chiron_engine** out) {
+  if (!out) return fail(CHIRON_ERR_INVALID, "null out");
+  *out = nullptr;
+  chiron_status st = validate_desc(desc);
+  if (st) return st;
+  if (!weights || !opts) return fail(CHIRON_ERR_INVALID, "null weights/opts");
+  size_t want = 0;
+  chiron_weights_size(desc, &want);
+  if (want != n_floats) return fail(CHIRON_ERR_INVALID, "weight blob has %zu floats, descriptor needs %zu", n_floats, want);
+  if (opts->max_batch < 1 || opts->segment_len < 1) return fail(CHIRON_ERR_INVALID, "max_batch/segment_len must be positive");
+  if (opts->dtype != CHIRON_F32) return fail(CHIRON_ERR_INVALID, "dtype %d not available in this build (fp32 parity path only)", opts->dtype);
+  if (desc->hidden != 100) return fail(CHIRON_ERR_INVALID, "hidden=%d: the recurrence kernel is built for hidden=100 (both shipped models)", desc->hidden);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CHIRON_ERR_DEVICE, "no HIP device visible: libchiron_amd has no CPU fallback");
+  if (opts->device_id < 0 || opts->device_id >= ndev) return fail(CHIRON_ERR_INVALID, "device_id %d out of range (%d devices)", opts->device_id, ndev);
+  HIP_TRY(hipSetDevice(opts->device_id));
+
+  chiron_engine* e = new chiron_engine();
+  e->desc = *desc;
+  e->opts = *opts;
+  if (e->opts.n_slots < 1) e->opts.n_slots = 1;
+  e->L = opts->segment_len;
+  e->H = desc->hidden;
+  e->K = desc->classes;
+  e->maxB = opts->max_batch;
+  e->BP = roundup(opts->max_batch, 16);
+  st = build_plans(e, weights);
+  if (st == CHIRON_OK) {
+    e->slots.resize(e->opts.n_slots);
+    for (Slot& s : e->slots)
+      if ((st = alloc_slot(e, &s))) break;
+  }
+  if (st == CHIRON_OK && hipDeviceSynchronize() != hipSuccess) st = fail(CHIRON_ERR_DEVICE, "device sync after setup failed");
+  if (st) {
+    chiron_engine_destroy(e);
+    return st;
+  }
+  e->prof_names = {"conv_gemm", "lstm_proj_gemm", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob"};
+  *out = e;
+  return CHIRON_OK;
+}
+
+extern "C" void chiron_engine_destroy(chiron_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->opts.device_id);
+  hipDeviceSynchronize();
+  for (Slot& s : e->slots) {
+    for (ProfEvent& ev : s.events) {
+      hipEventDestroy(ev.a);
+      hipEventDestroy(ev.b);
+    }
+    if (s.stream) hipStreamDestroy(s.stream);
+    void* hp[] = {s.h_sig, s.h_seq, s.h_indices, s.h_values, s.h_meta, s.h_log_prob, s.h_prob, s.h_logits};
+    for (void* q : hp)
+      if (q) hipHostFree(q);
+  }
+  for (void* q : e->owned) hipFree(q);
+  delete e;
+}
+
+extern "C" chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out_T, double* out_ratio) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  if (out_T) *out_T = e->T;
+  if (out_ratio) *out_ratio = (double)e->L / (double)e->T;  // chiron_model.py:151-152 (true division)
+  return CHIRON_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// launch sequence
+// ----------------------------------------------------------------------------------------------
+enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB };
+
+struct Prof {
+  chiron_engine* e;
+  Slot* s;
+  ProfEvent ev;
+  bool on;
+  Prof(chiron_engine* e_, Slot* s_, int name_id, double flops, double bytes) : e(e_), s(s_), on(e_->profiling) {
+    if (!on) return;
+    ev.name_id = name_id;
+    ev.flops = flops;
+    ev.bytes = bytes;
+    hipEventCreate(&ev.a);
+    hipEventCreate(&ev.b);
+    hipEventRecord(ev.a, s->stream);
+  }
+  ~Prof() {
+    if (!on) return;
+    hipEventRecord(ev.b, s->stream);
+    s->events.push_back(ev);
+  }
+};
+
+static void init_gemm(GemmParams* g, const ConvGemmPlan& w, int B, int BP) {
+  memset(g, 0, sizeof(*g));
+  g->B = B;
+  g->BP = BP;
+  g->N = w.N;
+  g->K = w.K;
+  g->Wt = w.Wt;
+  g->shift = w.shift;
+  g->z_dirs_total = 2;
+}
+
+static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
+  float* x = nullptr;  // block input (channels-last [B*T][C])
+  int xi = -1;         // which act buffer holds x
+  for (const BlockPlan& b : e->blocks) {
+    const int cop = roundup(b.c, GEMM_BK);
+    // pick two scratch buffers different from x
+    int ia = (xi + 1) % 3, ib = (xi + 2) % 3;
+    if (xi < 0) {
+      ia = 0;
+      ib = 1;
+    }
+    float* bufA = s->act[ia];
+    float* bufB = s->act[ib];
+    GemmParams g;
+    if (b.lift) {
+      // conv2b over the lifted signal: A(m, tap*C + c) = relu(sig*a[c] + b[c])
+      init_gemm(&g, b.gb, B, e->BP);
+      g.M = B * b.t_out;
+      g.T_out = b.t_out;
+      g.nseg = b.k;
+      for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{nullptr, 0, 0, b.c, cop, b.t_in, b.stride, j - b.left, 0};
+      g.relu = 1;
+      g.sig = sig;
+      g.L = e->L;
+      g.lift_a = b.lift_a;
+      g.lift_b = b.lift_b;
+      g.out = bufB;
+      g.ldo = b.c;
+      {
+        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * b.t_out * b.c);
+        launch_gemm(g, s->stream);
+      }
+      // conv2c + lifted branch1 + ReLU
+      init_gemm(&g, b.gc, B, e->BP);
+      g.M = B * b.t_out;
+      g.T_out = b.t_out;
+      g.nseg = 1;
+      g.seg[0] = GemmSeg{bufB, b.c, 0, b.c, cop, b.t_out, 1, 0, 0};
+      g.relu = 1;
+      g.sig = sig;
+      g.L = e->L;
+      g.res_a = b.res_a;
+      g.res_stride = b.stride;
+      g.out = bufA;
+      g.ldo = b.c;
+      {
+        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.c * b.c, 8.0 * B * b.t_out * b.c);
+        launch_gemm(g, s->stream);
+      }
+      x = bufA;
+      xi = ia;
+    } else {
+      const int cip = roundup(b.c_in, GEMM_BK);
+      // conv2a
+      init_gemm(&g, b.ga, B, e->BP);
+      g.M = B * b.t_in;
+      g.T_out = b.t_in;
+      g.nseg = 1;
+      g.seg[0] = GemmSeg{x, b.c_in, 0, b.c_in, cip, b.t_in, 1, 0, 0};
+      g.relu = 1;
+      g.out = bufA;
+      g.ldo = b.c;
+      {
+        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_in * (double)b.c_in * b.c, 4.0 * B * b.t_in * (b.c_in + b.c));
+        launch_gemm(g, s->stream);
+      }
+      // conv2b
+      init_gemm(&g, b.gb, B, e->BP);
+      g.M = B * b.t_out;
+      g.T_out = b.t_out;
+      g.nseg = b.k;
+      for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{bufA, b.c, 0, b.c, cop, b.t_in, b.stride, j - b.left, 0};
+      g.relu = 1;
+      g.out = bufB;
+      g.ldo = b.c;
+      {
+        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * (b.t_in + b.t_out) * b.c);
+        launch_gemm(g, s->stream);
+      }
+      // conv2c + branch1/conv1 fused along K, + ReLU
+      init_gemm(&g, b.gc, B, e->BP);
+      g.M = B * b.t_out;
+      g.T_out = b.t_out;
+      g.nseg = 2;
+      g.seg[0] = GemmSeg{bufB, b.c, 0, b.c, cop, b.t_out, 1, 0, 0};
+      g.seg[1] = GemmSeg{x, b.c_in, 0, b.c_in, cip, b.t_in, b.stride, 0, 0};
+      g.relu = 1;
+      g.out = bufA;
+      g.ldo = b.c;
+      {
+        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)(b.c + b.c_in) * b.c, 4.0 * B * b.t_out * (2.0 * b.c + b.c_in));
+        launch_gemm(g, s->stream);
+      }
+      x = bufA;
+      xi = ia;
+    }
+  }
+  s->sig_used = x;  // CNN feature [B*T][C]
+}
+
+static void run_rnn(chiron_engine* e, Slot* s, int B) {
+  const float* fea = s->sig_used;
+  const int T = e->T, H = e->H, BP = e->BP;
+  const int zc = e->tiles * 16;
+  const float* prev = nullptr;
+  for (size_t l = 0; l < e->lstm.size(); ++l) {
+    const LstmPlan& lp = e->lstm[l];
+    float* outbuf = s->lasth[l & 1];
+    for (int pj = 0; pj < lp.nproj; ++pj) {
+      GemmParams g;
+      init_gemm(&g, lp.proj[pj], B, BP);
+      g.M = T * BP;
+      g.T_out = T;
+      g.m_time_major = 1;
+      g.nseg = 1;
+      const int Kp = roundup(lp.in_w, GEMM_BK);
+      if (l == 0)
+        g.seg[0] = GemmSeg{fea, e->C, 0, e->C, Kp, T, 1, 0, 0};
+      else if (lp.nproj == 1)
+        g.seg[0] = GemmSeg{prev, 2 * H, 0, 2 * H, Kp, T, 1, 0, 1};
+      else
+        g.seg[0] = GemmSeg{prev, 2 * H, pj * H, H, Kp, T, 1, 0, 1};
+      g.out = s->z;
+      g.out_mode = 1;
+      g.z_tiles = e->tiles;
+      g.z_ndir = lp.nproj == 1 ? 2 : 1;
+      g.z_dir0 = lp.nproj == 1 ? 0 : pj;
+      const double ndir = lp.nproj == 1 ? 2.0 : 1.0;
+      Prof pr(e, s, PN_PROJ, 2.0 * B * T * (double)lp.in_w * 4 * H * ndir, 4.0 * B * T * (lp.in_w + ndir * zc));
+      launch_gemm(g, s->stream);
+    }
+    LstmParams r;
+    r.z = s->z;
+    r.wfrag = lp.wfrag;
+    r.seq_len = s->seq;
+    r.out = outbuf;
+    r.T = T;
+    r.B = B;
+    r.BP = BP;
+    r.H = H;
+    r.tiles = e->tiles;
+    r.hpz = e->hpz;
+    r.ndir = 2;
+    {
+      Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H, 4.0 * B * T * 2.0 * (zc + H));
+      launch_lstm(r, s->stream);
+    }
+    prev = outbuf;
+  }
+  FcParams f;
+  f.lasth = prev;
+  f.w = e->fc_w;
+  f.bias = e->fc_b;
+  f.wc = e->fc_wc;
+  f.bc = e->fc_bc;
+  f.logits = s->logits;
+  f.T = T;
+  f.B = B;
+  f.BP = BP;
+  f.H = H;
+  f.K = e->K;
+  {
+    Prof pr(e, s, PN_FC, 2.0 * B * T * (2.0 * H + (double)H * e->K), 4.0 * B * T * (2.0 * H + e->K));
+    launch_fc(f, s->stream);
+  }
+}
+
+extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, const float* x, const int32_t* seq_len,
+                                              int32_t batch, int32_t beam_width, uint32_t flags) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range (%zu slots)", slot, e->slots.size());
+  if (!x || !seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
+  if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
+  if (beam_width < 0) return fail(CHIRON_ERR_INVALID, "beam_width %d", beam_width);
+  if (beam_width > e->opts.max_beam) return fail(CHIRON_ERR_OVERFLOW, "beam_width %d exceeds max_beam %d given at create", beam_width, e->opts.max_beam);
+  Slot* s = &e->slots[slot];
+  HIP_TRY(hipSetDevice(e->opts.device_id));
+  if (s->busy) HIP_TRY(hipStreamSynchronize(s->stream));
+  const int B = batch, T = e->T, K = e->K;
+  const float* sig;
+  HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
+  if (flags & CHIRON_X_ON_DEVICE) {
+    sig = x;
+    HIP_TRY(hipMemcpyAsync(s->seq, seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
+  } else {
+    memcpy(s->h_sig, x, (size_t)B * e->L * 4);
+    memcpy(s->h_seq, seq_len, (size_t)B * 4);
+    HIP_TRY(hipMemcpyAsync(s->sig, s->h_sig, (size_t)B * e->L * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->seq, s->h_seq, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
+    sig = s->sig;
+  }
+  run_cnn(e, s, B, sig);
+  run_rnn(e, s, B);
+
+  if (beam_width == 0) {
+    GreedyParams g;
+    g.logits = s->logits;
+    g.seq_len = s->seq;
+    g.labels = s->labels;
+    g.count = s->count;
+    g.log_prob = s->log_prob;
+    g.prob_logits = (flags & CHIRON_WANT_PROB) ? s->prob : nullptr;
+    g.B = B;
+    g.T = T;
+    g.K = K;
+    Prof pr(e, s, PN_GREEDY, 0, 4.0 * B * T * K);
+    launch_greedy(g, s->stream);
+  } else {
+    if (flags & CHIRON_WANT_PROB) {
+      PathProbParams pp{s->logits, s->prob, B, T, K};
+      Prof pr(e, s, PN_PATHPROB, 0, 4.0 * B * T * K);
+      launch_path_prob(pp, s->stream);
+    }
+    BeamParams bp;
+    bp.logits = s->logits;
+    bp.seq_len = s->seq;
+    bp.labels = s->labels;
+    bp.count = s->count;
+    bp.log_prob = s->log_prob;
+    bp.workspace = s->beam_ws;
+    bp.workspace_bytes = s->beam_ws_bytes;
+    bp.B = B;
+    bp.T = T;
+    bp.K = K;
+    bp.beam = beam_width;
+    Prof pr(e, s, PN_BEAM, 0, 4.0 * B * T * K);
+    if (launch_beam(bp, s->stream) != 0) return fail(CHIRON_ERR_INVALID, "beam search launch rejected (beam_width %d)", beam_width);
+  }
+  {
+    SparseParams sp{s->labels, s->count, s->offsets, s->indices, s->values, s->meta, B, T};
+    Prof pr(e, s, PN_SPARSE, 0, 0);
+    launch_sparse(sp, s->stream);
+  }
+  HIP_TRY(hipMemcpyAsync(s->h_meta, s->meta, 3 * 8, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->h_log_prob, s->log_prob, (size_t)B * 4, hipMemcpyDeviceToHost, s->stream));
+  if (flags & CHIRON_WANT_PROB) HIP_TRY(hipMemcpyAsync(s->h_prob, s->prob, (size_t)B * 4, hipMemcpyDeviceToHost, s->stream));
+  if (flags & CHIRON_WANT_LOGITS)
+    HIP_TRY(hipMemcpyAsync(s->h_logits, s->logits, (size_t)B * T * K * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipGetLastError());
+  s->busy = true;
+  s->batch = B;
+  s->flags = flags;
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_engine_collect(chiron_engine* e, int32_t slot, chiron_decoded* out) {
+  if (!e || !out) return fail(CHIRON_ERR_INVALID, "null engine/out");
+  if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range", slot);
+  Slot* s = &e->slots[slot];
+  if (!s->busy) return fail(CHIRON_ERR_STATE, "collect on slot %d without a submitted batch", slot);
+  HIP_TRY(hipSetDevice(e->opts.device_id));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  const int64_t nnz = s->h_meta[0];
+  if (!(s->flags & CHIRON_NO_DECODE_COPY) && nnz > 0) {
+    HIP_TRY(hipMemcpyAsync(s->h_indices, s->indices, (size_t)nnz * 16, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_values, s->values, (size_t)nnz * 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  if (!(s->flags & CHIRON_WANT_PROB)) memset(s->h_prob, 0, (size_t)s->batch * 4);
+  out->nnz = nnz;
+  out->indices = s->h_indices;
+  out->values = s->h_values;
+  out->dense_shape[0] = s->h_meta[1];
+  out->dense_shape[1] = s->h_meta[2];
+  out->log_prob = s->h_log_prob;
+  out->prob_logits = s->h_prob;
+  out->logits = (s->flags & CHIRON_WANT_LOGITS) ? s->h_logits : nullptr;
+  out->batch = s->batch;
+  out->T = e->T;
+  s->busy = false;
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_engine_sync(chiron_engine* e) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->opts.device_id));
+  for (Slot& s : e->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_engine_device_results(chiron_engine* e, int32_t slot, const float** logits,
+                                                      const int64_t** indices, const int64_t** values,
+                                                      const int64_t** nnz_and_shape) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range", slot);
+  Slot* s = &e->slots[slot];
+  if (logits) *logits = s->logits;
+  if (indices) *indices = s->indices;
+  if (values) *values = s->values;
+  if (nnz_and_shape) *nnz_and_shape = s->meta;
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_engine_profile(chiron_engine* e, int32_t enable) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  chiron_status st = chiron_engine_sync(e);
+  if (st) return st;
+  for (Slot& s : e->slots) {
+    for (ProfEvent& ev : s.events) {
+      hipEventDestroy(ev.a);
+      hipEventDestroy(ev.b);
+    }
+    s.events.clear();
+  }
+  e->profiling = enable != 0;
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_engine_profile_read(chiron_engine* e, chiron_kernel_stat* stats, int32_t max_stats,
+                                                    int32_t* n_stats) {
+  if (!e || !stats || !n_stats) return fail(CHIRON_ERR_INVALID, "null argument");
+  chiron_status st = chiron_engine_sync(e);
+  if (st) return st;
+  std::vector<chiron_kernel_stat> acc(e->prof_names.size());
+  for (size_t i = 0; i < acc.size(); ++i) {
+    memset(&acc[i], 0, sizeof(acc[i]));
+    snprintf(acc[i].name, sizeof(acc[i].name), "%s", e->prof_names[i].c_str());
+  }
+  for (Slot& s : e->slots)
+    for (ProfEvent& ev : s.events) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.a, ev.b) != hipSuccess) continue;
+      chiron_kernel_stat& k = acc[ev.name_id];
+      k.total_ms += ms;
+      k.launches += 1;
+      k.flops += ev.flops;
+      k.bytes += ev.bytes;
+    }
+  int n = 0;
+  for (size_t i = 0; i < acc.size() && n < max_stats; ++i)
+    if (acc[i].launches > 0) stats[n++] = acc[i];
+  *n_stats = n;
+  return CHIRON_OK;
+}

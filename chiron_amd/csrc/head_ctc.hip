@@ -1,0 +1,240 @@
+// FC head, path_prob, greedy CTC decode and SparseTensor construction for gfx950.
+//
+//   fc_kernel        rnn.py:72-96  -- HBM-bound: reads lasth once.
+//   greedy_kernel    tf.nn.ctc_greedy_decoder(merge_repeated=True) (chiron_eval.py:485-487) and
+//                    path_prob (chiron_eval.py:116-136); one wave per segment, ballot/popcount
+//                    compaction.
+//   scan/scatter     the (indices, values, dense_shape) SparseTensor the reference dequeues
+//                    (chiron_eval.py:403-409), built on device.
+#include "kernels.h"
+
+namespace chiron {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// --------------------------------------------------------------------------------------------
+// FC head.  logits[b][t][k] = sum_u (h_fw[u]*w[0][u] + h_bw[u]*w[1][u] + bias[u]) * wc[u][k] + bc[k]
+// One wave per position (t,b): lanes 0..2H/4-1 each own 4 consecutive columns of the 2H-wide row.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int H = p.H, K = p.K;
+  const int nl = (2 * H) / 4;  // lanes carrying data (50 for H=100)
+
+  // per-lane folded weights: cw[j][k] = w[dir][u_j] * wc[u_j][k]
+  float cw[4][CHIRON_KMAX];
+  float cst[CHIRON_KMAX];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < CHIRON_KMAX; ++k) cw[j][k] = 0.f;
+  if (lane < nl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cidx = 4 * lane + j;  // column in [0, 2H)
+      const int d = cidx / H;
+      const int u = cidx - d * H;
+      const float wd = p.w[d * H + u];
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k)
+        if (k < K) cw[j][k] = wd * p.wc[u * K + k];
+    }
+  }
+  // constant term: sum_u bias[u]*wc[u][k] + bc[k]  (same for every position)
+#pragma unroll
+  for (int k = 0; k < CHIRON_KMAX; ++k) {
+    float s = 0.f;
+    if (k < K) {
+      for (int u = lane; u < H; u += 64) s += p.bias[u] * p.wc[u * K + k];
+    }
+    s = wave_sum(s);
+    cst[k] = (k < K) ? s + p.bc[k] : 0.f;
+  }
+
+  const long npos = (long)p.T * p.B;
+  for (long pos = wave; pos < npos; pos += nwaves) {
+    const int b = (int)(pos / p.T);
+    const int t = (int)(pos - (long)b * p.T);
+    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+    if (lane < nl) h = *reinterpret_cast<const f32x4*>(p.lasth + ((long)t * p.BP + b) * 2 * H + 4 * lane);
+    float acc[CHIRON_KMAX];
+#pragma unroll
+    for (int k = 0; k < CHIRON_KMAX; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = fmaf(h[j], cw[j][k], s);
+      acc[k] = wave_sum(s);
+    }
+    if (lane < K) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k)
+        if (lane == k) v = acc[k] + cst[k];
+      p.logits[pos * K + lane] = v;
+    }
+  }
+}
+
+void launch_fc(const FcParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(fc_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
+}
+
+// --------------------------------------------------------------------------------------------
+// Greedy CTC + path_prob: one wave per segment.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void greedy_kernel(const GreedyParams p) {
+  const int lane = threadIdx.x & 63;
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= p.B) return;
+  const int K = p.K, T = p.T;
+  const int blank = K - 1;
+  const int len = min(max(p.seq_len[b], 0), T);
+  const float* lg = p.logits + (long)b * T * K;
+  uint8_t* out = p.labels + (long)b * T;
+
+  float negsum = 0.f, diffsum = 0.f;
+  int base = 0;
+  int carry_k = -1;  // argmax of the last frame of the previous 64-frame group
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    int k = -1;
+    float m1 = 0.f, m2 = 0.f;
+    if (t < T) {
+      // first-max argmax (Eigen maxCoeff tie rule) and runner-up value
+      m1 = lg[t * K];
+      k = 0;
+      m2 = -INFINITY;
+      for (int j = 1; j < K; ++j) {
+        const float v = lg[t * K + j];
+        if (v > m1) {
+          m2 = m1;
+          m1 = v;
+          k = j;
+        } else if (v > m2) {
+          m2 = v;
+        }
+      }
+      diffsum += m1 - m2;
+      if (t < len) negsum -= m1;
+    }
+    int prev = __shfl_up(k, 1);
+    if (lane == 0) prev = carry_k;
+    carry_k = __shfl(k, 63);
+    const bool emit = (t < len) && (k != blank) && (k != prev);
+    const unsigned long long mask = __ballot(emit);
+    if (emit) {
+      const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      out[pos] = (uint8_t)k;
+    }
+    base += __popcll(mask);
+  }
+  negsum = wave_sum(negsum);
+  diffsum = wave_sum(diffsum);
+  if (lane == 0) {
+    p.count[b] = base;
+    p.log_prob[b] = negsum;
+    if (p.prob_logits) p.prob_logits[b] = diffsum / (float)T;
+  }
+}
+
+void launch_greedy(const GreedyParams& p, hipStream_t stream) {
+  const int blocks = (p.B + 3) / 4;
+  hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(256), 0, stream, p);
+}
+
+__global__ __launch_bounds__(256) void path_prob_kernel(const PathProbParams p) {
+  const int lane = threadIdx.x & 63;
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= p.B) return;
+  const float* lg = p.logits + (long)b * p.T * p.K;
+  float s = 0.f;
+  for (int t = lane; t < p.T; t += 64) {
+    float m1 = lg[t * p.K], m2 = -INFINITY;
+    for (int j = 1; j < p.K; ++j) {
+      const float v = lg[t * p.K + j];
+      if (v > m1) {
+        m2 = m1;
+        m1 = v;
+      } else if (v > m2) {
+        m2 = v;
+      }
+    }
+    s += m1 - m2;
+  }
+  s = wave_sum(s);
+  if (lane == 0) p.prob_logits[b] = s / (float)p.T;
+}
+
+void launch_path_prob(const PathProbParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(path_prob_kernel, dim3((p.B + 3) / 4), dim3(256), 0, stream, p);
+}
+
+// --------------------------------------------------------------------------------------------
+// SparseTensor build: exclusive scan of the per-row counts (one workgroup), then scatter.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_kernel(const SparseParams p) {
+  __shared__ long part[1024];
+  __shared__ int pmax[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (p.B + 1023) / 1024;
+  const int lo = min(tid * chunk, p.B), hi = min(lo + chunk, p.B);
+  long s = 0;
+  int mx = 0;
+  for (int i = lo; i < hi; ++i) {
+    s += p.count[i];
+    mx = max(mx, p.count[i]);
+  }
+  part[tid] = s;
+  pmax[tid] = mx;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    long v = 0;
+    int m = 0;
+    if (tid >= o) {
+      v = part[tid - o];
+      m = pmax[tid - o];
+    }
+    __syncthreads();
+    part[tid] += v;
+    pmax[tid] = max(pmax[tid], m);
+    __syncthreads();
+  }
+  long run = part[tid] - s;  // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) {
+    p.offsets[i] = run;
+    run += p.count[i];
+  }
+  if (tid == 1023) {
+    p.offsets[p.B] = part[1023];
+    p.meta[0] = part[1023];
+    p.meta[1] = p.B;
+    p.meta[2] = pmax[1023];
+  }
+}
+
+__global__ __launch_bounds__(64) void scatter_kernel(const SparseParams p) {
+  const int b = blockIdx.x;
+  const long off = p.offsets[b];
+  const int n = p.count[b];
+  const uint8_t* src = p.labels + (long)b * p.T;
+  for (int j = threadIdx.x; j < n; j += 64) {
+    p.indices[(off + j) * 2] = b;
+    p.indices[(off + j) * 2 + 1] = j;
+    p.values[off + j] = src[j];
+  }
+}
+
+void launch_sparse(const SparseParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+  hipLaunchKernelGGL(scatter_kernel, dim3(p.B), dim3(64), 0, stream, p);
+}
+
+}  // namespace chiron

@@ -1,0 +1,148 @@
+// Internal launch interface between the engine (engine.hip) and the gfx950 kernels.
+// Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CHIRON_KMAX 5  // classes upper bound (reference: class_n = 5, rnn.py:25)
+
+namespace chiron {
+
+// ---------------------------------------------------------------------------------------------
+// Fused conv / projection GEMM on v_mfma_f32_32x32x2_f32  (gemm.hip)
+//
+//   out[row(m)][n] = act( sum_k A(m,k) * Wt[n][k] + shift[n] + residual(m,n) )
+//
+// A(m,k) is assembled on the fly from up to GEMM_MAX_SEG K-segments (conv taps, or the fused
+// branch1 input), each a strided/shifted view of an activation tensor -- or synthesised from the raw
+// signal ("lift": the 1->C conv + BN + ReLU of res_layer1/branch2/conv2a is never materialised).
+// ---------------------------------------------------------------------------------------------
+constexpr int GEMM_MAX_SEG = 16;
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_BK = 32;
+
+struct GemmSeg {
+  const float* src;  // activation tensor [rows][lda]; nullptr => lift from the signal
+  int lda;           // row stride of src in floats
+  int col0;          // first column of src used by this segment
+  int cin;           // channels taken (K extent of the segment, before padding to GEMM_BK)
+  int kpad;          // cin rounded up to GEMM_BK: K extent occupied in Wt
+  int w_in;          // positions per sequence in src (conv mode)
+  int stride;        // conv stride
+  int shift;         // tap offset: in_t = t_out*stride + shift
+  int time_major;    // src rows are (t*BP + b) instead of (b*w_in + in_t)
+};
+
+struct GemmParams {
+  int M;        // output rows (conv: B*T_out; projection: T*BP)
+  int T_out;    // conv mode: positions per sequence of the output
+  int B;        // valid batch rows
+  int BP;       // batch padded to 16 (projection / time-major modes)
+  int m_time_major;  // 1: m = t*BP + b (LSTM projection), 0: m = b*T_out + t (conv)
+  int N;        // valid output columns
+  int K;        // total padded K (sum of kpad)
+  int nseg;
+  GemmSeg seg[GEMM_MAX_SEG];
+  const float* Wt;     // [Npad][K], k contiguous, zero padded; Npad multiple of GEMM_BN
+  const float* shift;  // [Npad] added before activation (folded BN offset / LSTM bias), may be null
+  int relu;
+  // lift (segments with src == nullptr): A = relu(sig[b][in_t]*lift_a[c] + lift_b[c]), 0 outside
+  const float* sig;    // [B][L]
+  int L;
+  const float* lift_a;
+  const float* lift_b;
+  // residual synthesised from the signal (res_layer1/branch1: 1x1 conv on the signal + BN):
+  //   + sig[b][t_out*res_stride] * res_a[n]      (its BN offset is folded into shift[])
+  const float* res_a;
+  int res_stride;
+  // output
+  float* out;
+  int ldo;         // row stride (out_mode 0)
+  int out_mode;    // 0: out[m*ldo + n];  1: LSTM z fragment layout (see lstm.hip)
+  int z_tiles;     // out_mode 1: 16-column tiles per direction (4 gates * HP/16)
+  int z_ndir;      // out_mode 1: directions interleaved in N (N = z_ndir * z_tiles * 16)
+  int z_dir0;      // out_mode 1: first direction index written by this launch
+  int z_dirs_total;  // out_mode 1: directions in the z buffer (2)
+};
+
+void launch_gemm(const GemmParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// LSTM recurrence (lstm.hip): one workgroup = 16 batch rows x one direction x all T steps.
+// ---------------------------------------------------------------------------------------------
+constexpr int LSTM_ROWS = 16;     // batch rows per workgroup (one 16x16x4 MFMA tile in M)
+constexpr int LSTM_WAVES = 4;
+constexpr int LSTM_UB_PER_WAVE = 2;  // 16-unit blocks owned by one wave
+constexpr int LSTM_HP = 128;      // hidden padded: LSTM_WAVES*LSTM_UB_PER_WAVE*16 (z stores HPZ)
+
+struct LstmParams {
+  const float* z;        // [T][NBT][ndir][tiles][4 rowgroups][16 cols][4 regs]  (x-projection + bias)
+  const float* wfrag;    // [ndir][LSTM_WAVES][8 tiles][KSTEPS][64 lanes] recurrent weights, fragment order
+  const int32_t* seq_len;  // [BP] (0 for padded rows)
+  float* out;            // lasth [T][BP][ndir*H] time major
+  int T, B, BP, H;       // H = hidden (<= 100 .. 128)
+  int tiles;             // 16-column tiles per direction in z
+  int hpz;               // padded hidden in z (multiple of 16)
+  int ndir;              // 2
+};
+void launch_lstm(const LstmParams& p, hipStream_t stream);
+int lstm_ksteps(int H);
+
+// ---------------------------------------------------------------------------------------------
+// FC head + CTC (head_ctc.hip)
+// ---------------------------------------------------------------------------------------------
+struct FcParams {
+  const float* lasth;  // [T][BP][2H] time major
+  const float* w;      // [2][H]
+  const float* bias;   // [H]
+  const float* wc;     // [H][K]
+  const float* bc;     // [K]
+  float* logits;       // [B][T][K]
+  int T, B, BP, H, K;
+};
+void launch_fc(const FcParams& p, hipStream_t stream);
+
+struct GreedyParams {
+  const float* logits;      // [B][T][K]
+  const int32_t* seq_len;   // [B]
+  uint8_t* labels;          // [B][T] decoded labels (dense, first count[b] valid)
+  int32_t* count;           // [B]
+  float* log_prob;          // [B] -sum of max logits over t < seq_len
+  float* prob_logits;       // [B] path_prob (mean over ALL T of top1-top2), or nullptr
+  int B, T, K;
+};
+void launch_greedy(const GreedyParams& p, hipStream_t stream);
+
+struct SparseParams {
+  const uint8_t* labels;  // [B][T]
+  const int32_t* count;   // [B]
+  int64_t* offsets;       // [B+1] scratch
+  int64_t* indices;       // [nnz][2]
+  int64_t* values;        // [nnz]
+  int64_t* meta;          // [3]: nnz, batch, max_len
+  int B, T;
+};
+void launch_sparse(const SparseParams& p, hipStream_t stream);
+
+struct BeamParams {
+  const float* logits;     // [B][T][K]
+  const int32_t* seq_len;  // [B]
+  uint8_t* labels;         // [B][T]
+  int32_t* count;          // [B]
+  float* log_prob;         // [B]
+  void* workspace;         // trie nodes
+  size_t workspace_bytes;
+  int B, T, K, beam;
+};
+size_t beam_workspace_bytes(int B, int T, int beam);
+int launch_beam(const BeamParams& p, hipStream_t stream);  // returns 0 on success
+
+struct PathProbParams {
+  const float* logits;
+  float* prob_logits;
+  int B, T, K;
+};
+void launch_path_prob(const PathProbParams& p, hipStream_t stream);
+
+}  // namespace chiron

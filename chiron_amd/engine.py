@@ -1,0 +1,149 @@
+"""Python face of the C ABI: one Engine per GPU.
+
+Mirrors the reference seam `chiron_model.inference` (chiron_model.py:134-172) +
+the decode sub-graph (chiron_eval.py:465-492): feed (x[B,L] f32, seq_len[B]
+i32) -> (SparseTensor(indices, values, dense_shape), log_prob, prob_logits,
+logits), the SavedModel PREDICT signature of export_test.py:103-112.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from .model import ModelSpec
+
+SparseTensor = namedtuple("SparseTensor", "indices values dense_shape")      # chiron_eval.py:34
+DecodeResult = namedtuple("DecodeResult", "decoded log_prob prob_logits logits")
+
+
+def _is_torch_cuda(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and x.is_cuda
+
+
+class Engine(object):
+    def __init__(self, spec, weights, max_batch, segment_len, device_id=0, n_slots=1, max_beam=0, dtype="fp32"):
+        if not isinstance(spec, ModelSpec):
+            raise TypeError("spec must be a ModelSpec")
+        self._lib = _lib.load()
+        self.spec = spec
+        blob = spec.pack(weights) if isinstance(weights, dict) else np.ascontiguousarray(weights, dtype=np.float32)
+        desc = spec.to_c()
+        need = C.c_size_t()
+        _lib.check(self._lib.chiron_weights_size(C.byref(desc), C.byref(need)))
+        if need.value != blob.size:
+            raise ValueError("weight blob has %d floats, descriptor needs %d" % (blob.size, need.value))
+        opts = _lib.EngineOpts(device_id, max_batch, segment_len, n_slots,
+                               _lib.F32 if dtype == "fp32" else _lib.F16, max_beam)
+        h = C.c_void_p()
+        _lib.check(self._lib.chiron_engine_create(C.byref(desc), blob.ctypes.data_as(C.c_void_p), blob.size,
+                                                  C.byref(opts), C.byref(h)))
+        self._h = h
+        t, r = C.c_int32(), C.c_double()
+        _lib.check(self._lib.chiron_engine_dims(self._h, C.byref(t), C.byref(r)))
+        self.T = t.value
+        self.ratio = r.value
+        self.max_batch = max_batch
+        self.segment_len = segment_len
+        self.n_slots = n_slots
+        self.device_id = device_id
+        self._keep = [None] * n_slots      # keep submitted arrays alive until collect
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.chiron_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------
+    def submit(self, slot, x, seq_len, beam_width=0, want_prob=True, want_logits=False, copy_decoded=True):
+        """Asynchronous: enqueue one batch on `slot`'s stream.  x/seq_len may be
+        numpy arrays (host) or torch CUDA tensors already resident on this
+        engine's device (zero-copy)."""
+        flags = 0
+        if _is_torch_cuda(x):
+            if not (_is_torch_cuda(seq_len)):
+                raise TypeError("x on device requires seq_len on device too")
+            import torch
+            if x.dtype != torch.float32 or seq_len.dtype != torch.int32:
+                raise TypeError("device inputs must be float32 / int32")
+            x = x.contiguous()
+            seq_len = seq_len.contiguous()
+            batch = x.shape[0]
+            if x.dim() != 2 or x.shape[1] != self.segment_len:
+                raise ValueError("x must be [batch, %d]" % self.segment_len)
+            xp, sp = C.c_void_p(x.data_ptr()), C.c_void_p(seq_len.data_ptr())
+            flags |= _lib.X_ON_DEVICE
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
+            if x.ndim != 2 or x.shape[1] != self.segment_len:
+                raise ValueError("x must be [batch, %d], got %s" % (self.segment_len, x.shape))
+            batch = x.shape[0]
+            xp, sp = x.ctypes.data_as(C.c_void_p), seq_len.ctypes.data_as(C.c_void_p)
+        if seq_len.shape[0] != batch:
+            raise ValueError("seq_len must have one entry per row")
+        if want_prob:
+            flags |= _lib.WANT_PROB
+        if want_logits:
+            flags |= _lib.WANT_LOGITS
+        if not copy_decoded:
+            flags |= _lib.NO_DECODE_COPY
+        self._keep[slot] = (x, seq_len)
+        _lib.check(self._lib.chiron_engine_submit(self._h, slot, xp, sp, batch, int(beam_width), flags))
+
+    def collect(self, slot):
+        """Blocks; returns DecodeResult with numpy copies (valid indefinitely)."""
+        d = _lib.Decoded()
+        _lib.check(self._lib.chiron_engine_collect(self._h, slot, C.byref(d)))
+        self._keep[slot] = None
+        nnz, B, T, K = d.nnz, d.batch, d.T, self.spec.classes
+        if nnz > 0 and d.indices:
+            idx = np.ctypeslib.as_array(d.indices, shape=(nnz, 2)).copy()
+            val = np.ctypeslib.as_array(d.values, shape=(nnz,)).copy()
+        else:
+            idx = np.zeros((0, 2), dtype=np.int64)
+            val = np.zeros((0,), dtype=np.int64)
+        shape = np.asarray([d.dense_shape[0], d.dense_shape[1]], dtype=np.int64)
+        lp = np.ctypeslib.as_array(d.log_prob, shape=(B, 1)).copy()
+        pr = np.ctypeslib.as_array(d.prob_logits, shape=(B, 1)).copy()
+        lg = np.ctypeslib.as_array(d.logits, shape=(B, T, K)).copy() if d.logits else None
+        return DecodeResult(SparseTensor(idx, val, shape), lp, pr, lg)
+
+    def infer(self, x, seq_len, beam_width=0, want_prob=True, want_logits=False, slot=0):
+        self.submit(slot, x, seq_len, beam_width, want_prob, want_logits)
+        return self.collect(slot)
+
+    def sync(self):
+        _lib.check(self._lib.chiron_engine_sync(self._h))
+
+    def device_results(self, slot):
+        p = [C.c_void_p() for _ in range(4)]
+        _lib.check(self._lib.chiron_engine_device_results(self._h, slot, *[C.byref(q) for q in p]))
+        return tuple(q.value for q in p)
+
+    # ------------------------------------------------------------------
+    def profile(self, enable=True):
+        _lib.check(self._lib.chiron_engine_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        arr = (_lib.KernelStat * 16)()
+        n = C.c_int32()
+        _lib.check(self._lib.chiron_engine_profile_read(self._h, arr, 16, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            s = arr[i]
+            out[s.name.decode()] = {"total_ms": s.total_ms, "launches": s.launches, "flops": s.flops, "bytes": s.bytes}
+        return out
+
+
+def seq_len_for_engine(lengths, ratio):
+    """chiron_eval.py:337: np.round(seq_len/ratio).astype(np.int32) (round half even)."""
+    return np.round(np.asarray(lengths, dtype=np.float64) / ratio).astype(np.int32)

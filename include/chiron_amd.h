@@ -1,0 +1,188 @@
+/*
+ * chiron_amd.h -- C ABI of libchiron_amd.so, the MI355X (gfx950) basecalling
+ * inference engine that replaces the TensorFlow session behind the reference's
+ * `chiron call` hot path.
+ *
+ * The reference has no FFI layer; its seam is the pair of sess.run calls in
+ * chiron/chiron_eval.py (feed: :335-342, drain: :403-409), formalised by the
+ * SavedModel PREDICT signature in chiron/export_test.py:103-112
+ *   (x, seq_len) -> (indices, values, dense_shape, logits, prob_logits, log_prob).
+ * Every entry point below cites the reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a
+ * chiron_status (0 = OK) and never throws; chiron_last_error() returns a
+ * thread-local description of the last failure.  Host buffers belong to the
+ * caller; device buffers, streams and weights belong to the engine; result
+ * pointers stay valid until the next submit on the same slot.
+ */
+#ifndef CHIRON_AMD_H
+#define CHIRON_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHIRON_ABI_VERSION 1
+#define CHIRON_MAX_BLOCKS 8
+#define CHIRON_CLASSES 5 /* A,C,G,T,blank (rnn.py:25 class_n=5) */
+
+typedef enum {
+  CHIRON_OK = 0,
+  CHIRON_ERR_INVALID = 1,   /* bad argument / unsupported topology          */
+  CHIRON_ERR_DEVICE = 2,    /* HIP runtime failure (no GPU, OOM, launch)     */
+  CHIRON_ERR_STATE = 3,     /* collect without submit, slot out of range ... */
+  CHIRON_ERR_OVERFLOW = 4   /* batch > max_batch, beam > limit               */
+} chiron_status;
+
+/* One residual block, chiron/cnn.py:234-262 residual_layer():
+ *   branch1 = conv 1x1 (stride) [+BN iff i_bn];  branch2 = 1x1+BN+ReLU ->
+ *   1xk (stride)+BN+ReLU -> 1x1+BN;  out = ReLU(branch1 + branch2).          */
+typedef struct {
+  int32_t in_channels;  /* 1 for the first block (raw signal)                 */
+  int32_t out_channels; /* 256                                                */
+  int32_t k;            /* width of conv2b: 3 (DNA), 13 (shipped RNA block 1) */
+  int32_t stride;       /* stride of conv2b and branch1/conv1                 */
+  int32_t i_bn;         /* BN on branch1 (only res_layer1, cnn.py:382-384)    */
+} chiron_res_block;
+
+typedef enum {
+  CHIRON_RNN_STACK = 0, /* rnn.py:20-97  stack_bidirectional_dynamic_rnn (DNA) */
+  CHIRON_RNN_MULTI = 1  /* rnn.py:99-174 bidirectional_dynamic_rnn(MultiRNNCell) (RNA) */
+} chiron_rnn_kind;
+
+typedef enum {
+  CHIRON_BN_POPULATION = 0, /* cnn.py:125-163 batchnorm() inference branch (shipped checkpoints) */
+  CHIRON_BN_BATCH = 1       /* cnn.py:166-188 simple_global_bn (HEAD code)                        */
+} chiron_bn_mode;
+
+/* Topology descriptor: what chiron_model.read_config (chiron_model.py:37-48)
+ * plus the checkpoint's variable shapes determine.                           */
+typedef struct {
+  int32_t n_blocks;
+  chiron_res_block blocks[CHIRON_MAX_BLOCKS];
+  int32_t rnn_kind;   /* chiron_rnn_kind                                      */
+  int32_t rnn_layers; /* 3                                                    */
+  int32_t hidden;     /* 100                                                  */
+  int32_t classes;    /* 5                                                    */
+  int32_t bn_mode;    /* chiron_bn_mode                                       */
+} chiron_model_desc;
+
+/* Weight blob layout (float32, little endian), in this order:
+ *  for each block b:
+ *     branch1/conv1/weights            [1][in][out]        (TF HWIO, H squeezed)
+ *     if i_bn: conv1_bn scale, offset, pop_mean, pop_var   4 x [out]
+ *     branch2/conv2a/weights           [1][in][out]
+ *     conv2a_bn scale, offset, pop_mean, pop_var           4 x [out]
+ *     branch2/conv2b/weights           [k][out][out]
+ *     conv2b_bn ...                                        4 x [out]
+ *     branch2/conv2c/weights           [1][out][out]
+ *     conv2c_bn ...                                        4 x [out]
+ *  for each rnn layer l, for dir in (fw, bw):
+ *     lstm_cell/kernel                 [(in_l + H)][4H]    columns i|j|f|o
+ *     lstm_cell/bias                   [4H]
+ *       in_l: layer 0 -> out_channels of the last block;
+ *             STACK l>0 -> 2H ; MULTI l>0 -> H
+ *  rnn_fnn_layer/weights [2][H], bias [H], weights_class [H][K], bias_class [K]
+ * (in CHIRON_BN_BATCH mode the pop_mean/pop_var slots are present but unused.) */
+chiron_status chiron_weights_size(const chiron_model_desc* desc, size_t* n_floats);
+
+typedef enum { CHIRON_F32 = 0, CHIRON_F16 = 1 } chiron_dtype;
+
+typedef struct {
+  int32_t device_id;    /* HIP device ordinal                                 */
+  int32_t max_batch;    /* FLAGS.batch_size (chiron_eval.py:248)              */
+  int32_t segment_len;  /* FLAGS.segment_len                                  */
+  int32_t n_slots;      /* in-flight batches (>=1); each has its own stream   */
+  int32_t dtype;        /* chiron_dtype; CHIRON_F32 is the parity path        */
+  int32_t max_beam;     /* largest beam_width that will be requested (0=greedy only) */
+} chiron_engine_opts;
+
+typedef struct chiron_engine chiron_engine;
+
+/* Replaces build_eval_graph + Saver.restore (chiron_eval.py:244-276).        */
+chiron_status chiron_engine_create(const chiron_model_desc* desc, const float* weights, size_t n_floats,
+                                   const chiron_engine_opts* opts, chiron_engine** out);
+void chiron_engine_destroy(chiron_engine* e);
+
+/* T = number of logits frames per segment and ratio = segment_len / T
+ * (chiron_model.py:151-152).                                                 */
+chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out_T, double* out_ratio);
+
+/* flags for submit */
+#define CHIRON_X_ON_DEVICE 1u   /* x / seq_len are device pointers on opts.device_id */
+#define CHIRON_WANT_PROB 2u     /* compute prob_logits = path_prob (chiron_eval.py:116-136, -e fastq) */
+#define CHIRON_WANT_LOGITS 4u   /* copy logits [B,T,K] back on collect                */
+#define CHIRON_NO_DECODE_COPY 8u /* leave decoded sparse tensor on the device (bench)  */
+
+/* Replaces sess.run(logits_enqueue, feed_dict) (chiron_eval.py:335-342) plus the
+ * decode sub-graph (chiron_eval.py:465-492).  x: float32 [batch, segment_len]
+ * row-major; seq_len: int32 [batch], ALREADY divided by ratio and rounded
+ * half-even by the caller (chiron_eval.py:337).  beam_width 0 = greedy
+ * (merge_repeated=True), >0 = CTC beam search (merge_repeated=False, top_paths=1).
+ * Asynchronous: work is enqueued on the slot's stream.                         */
+chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, const float* x, const int32_t* seq_len,
+                                   int32_t batch, int32_t beam_width, uint32_t flags);
+
+/* The reference's decoded tuple (chiron_eval.py:403-409): SparseTensor
+ * (indices, values, dense_shape) + log_prob + prob_logits (+ logits).          */
+typedef struct {
+  int64_t nnz;
+  const int64_t* indices;   /* [nnz,2] (row, position), row-major sorted        */
+  const int64_t* values;    /* [nnz] in 0..3                                    */
+  int64_t dense_shape[2];   /* [batch, max decoded length]                      */
+  const float* log_prob;    /* [batch,1] greedy: -sum max logit; beam: log p    */
+  const float* prob_logits; /* [batch,1] path_prob, or zeros without WANT_PROB  */
+  const float* logits;      /* [batch,T,K] or NULL                              */
+  int32_t batch;
+  int32_t T;
+} chiron_decoded;
+
+/* Replaces sess.run(decode dequeue) (chiron_eval.py:403-409).  Blocks until the
+ * slot's work is complete, then fills *out with host pointers owned by the slot. */
+chiron_status chiron_engine_collect(chiron_engine* e, int32_t slot, chiron_decoded* out);
+
+/* Blocks until every slot's stream is idle. */
+chiron_status chiron_engine_sync(chiron_engine* e);
+
+/* Device pointers of a slot's most recent results (valid after collect/sync):
+ * logits [B,T,K] f32, and the decoded sparse tensor left on device.            */
+chiron_status chiron_engine_device_results(chiron_engine* e, int32_t slot, const float** logits,
+                                           const int64_t** indices, const int64_t** values,
+                                           const int64_t** nnz_and_shape /* [3]: nnz,batch,maxlen */);
+
+/* Per-kernel timing with HIP events on the engine's own streams (bench.py
+ * roofline).  Enable, run, sync, then read.                                    */
+typedef struct {
+  char name[48];
+  double total_ms;     /* sum of hipEventElapsedTime over launches              */
+  int64_t launches;
+  double flops;        /* algorithmic FLOPs summed over those launches          */
+  double bytes;        /* algorithmic HBM bytes summed over those launches      */
+} chiron_kernel_stat;
+chiron_status chiron_engine_profile(chiron_engine* e, int32_t enable);
+chiron_status chiron_engine_profile_read(chiron_engine* e, chiron_kernel_stat* stats, int32_t max_stats,
+                                         int32_t* n_stats);
+
+/* Overlap-consensus vote, chiron/utils/easy_assembler.py:
+ *   glue_kernal :276-294, stick_kernal :296-300, simple_assembly(_qs) :302-335 / :393-432,
+ *   add_count(_qs) :381-387 / :435-442, and the argmax of chiron_eval.py:457.
+ * bases: concatenated segments as 0..3; seg_off [n_seg+1] prefix offsets;
+ * seg_qs [n_seg] per-segment quality (may be NULL); kernel: 1 = glue, 2 = stick.
+ * Outputs (caller-allocated, capacity cap columns): counts [4][cap] float64,
+ * qs_sum [4][cap] float64 (if seg_qs), *out_len = consensus length.
+ * Returns CHIRON_ERR_OVERFLOW if cap is too small (then *out_len = needed).    */
+#define CHIRON_KERNAL_GLUE 1
+#define CHIRON_KERNAL_STICK 2
+chiron_status chiron_assemble(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs,
+                              int32_t kernal, double* counts, double* qs_sum, int64_t cap, int64_t* out_len);
+
+const char* chiron_last_error(void);
+int32_t chiron_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHIRON_AMD_H */
