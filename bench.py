@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: kilobases/s basecalled, DNA_default, segment_len=400, jump=390, batch=1100,
+greedy decode, synthetic 4 kHz signal (BASELINE.json configs[1]).
+
+One process per GPU (driver launches torch.distributed.run for N>1).  Reads shard per rank, no
+data-path collective ("scaling": "weak": every rank runs K batches of 1100 windows).
+
+A step = one pass of the hot path over one batch of 1100 windows whose signal is already resident
+in HBM: CNN -> 3x BiLSTM -> FC -> greedy CTC -> SparseTensor on device, decoded tensor copied to
+the host, per-read regroup + glue overlap-consensus vote on the host.  Two batches are kept in
+flight (two engine slots / HIP streams).
+
+value = signal-normalised kbases/s = windows * jump / (4000 Hz / 450 b/s) / seconds / 1000
+(SURVEY.md 8d (i)); decoded consensus bases/s with the synthetic weights is reported in "extra".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEG_LEN, JUMP, BATCH = 400, 390, 1100
+SAMPLES_PER_BASE = 4000.0 / 450.0
+BASES_PER_WINDOW = JUMP / SAMPLES_PER_BASE            # 43.875
+LSTM_GEMM_FLOP_PER_WINDOW = 611.84e6
+MODEL_FLOP_PER_WINDOW = 1.451e9
+PEAK_F32_MFMA_TFLOPS = 157.3                          # MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+READ_SAMPLES = 100000                                 # configs[3]: 100k-sample reads -> 257 windows
+
+
+def make_batches(n_batches, rank):
+    """Windows of synthetic reads, packed across reads into full batches (chiron_eval.py:321-334)."""
+    import chiron_amd as ca
+    from chiron_amd import signal_io
+    win_per_read = -(-READ_SAMPLES // JUMP)
+    n_reads = -(-n_batches * BATCH // win_per_read) + 1
+    xs, lens, tags = [], [], []
+    for r in range(n_reads):
+        sig = ca.synthetic_signal(1, READ_SAMPLES, seed=1234 + 1000 * rank + r)[0]
+        ev, ln = signal_io.window_signal(sig, 0, JUMP, SEG_LEN)
+        xs.append(ev)
+        lens.append(ln)
+        tags += [(r, i) for i in range(len(ln))]
+    x = np.concatenate(xs)[:n_batches * BATCH]
+    ln = np.concatenate(lens)[:n_batches * BATCH]
+    tags = tags[:n_batches * BATCH]
+    return (x.reshape(n_batches, BATCH, SEG_LEN), ln.reshape(n_batches, BATCH), tags, win_per_read)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import chiron_amd as ca
+    from chiron_amd import assembly
+    spec = ca.dna_default_spec()
+    weights = ca.synthetic_weights(spec, seed=1234)
+    eng = ca.Engine(spec, weights, max_batch=BATCH, segment_len=SEG_LEN, device_id=local_rank, n_slots=2)
+
+    n_distinct = 4
+    xb, lb, tags, win_per_read = make_batches(n_distinct, rank)
+    dev = torch.device("cuda", local_rank)
+    x_dev = [torch.from_numpy(xb[i]).to(dev) for i in range(n_distinct)]
+    s_dev = [torch.from_numpy(ca.seq_len_for_engine(lb[i], eng.ratio)).to(dev) for i in range(n_distinct)]
+    torch.cuda.synchronize()
+
+    decoded_bases = [0]
+    consensus_bases = [0]
+
+    def consume(res):
+        """host side of a step: ragged split of the SparseTensor + glue consensus over the batch rows"""
+        idx, val = res.decoded.indices, res.decoded.values
+        decoded_bases[0] += int(val.shape[0])
+        if val.shape[0]:
+            counts = np.bincount(idx[:, 0], minlength=BATCH)
+            keep = counts[counts > 0]
+            off = np.concatenate([[0], np.cumsum(keep)]).astype(np.int64)
+            cons = assembly.assemble_native(val.astype(np.uint8), off, None, "glue")
+            consensus_bases[0] += int(cons[0].shape[1])
+
+    def step(i, pending):
+        slot = i % 2
+        if pending[slot]:
+            consume(eng.collect(slot))
+        eng.submit(slot, x_dev[i % n_distinct], s_dev[i % n_distinct], beam_width=0, want_prob=True)
+        pending[slot] = True
+
+    def drain(pending):
+        for slot in (0, 1):
+            if pending[slot]:
+                consume(eng.collect(slot))
+                pending[slot] = False
+
+    pending = [False, False]
+    for i in range(args.warmup):
+        step(i, pending)
+    drain(pending)
+    eng.sync()
+    decoded_bases[0] = consensus_bases[0] = 0
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, pending)
+    drain(pending)
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        agg = torch.tensor([decoded_bases[0], consensus_bases[0]], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        decoded_bases[0], consensus_bases[0] = int(agg[0].item()), int(agg[1].item())
+
+    windows = args.steps * BATCH * world
+    kbases = windows * BASES_PER_WINDOW / 1000.0
+    value = kbases / dt
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel timing with HIP events on the engine's own stream (separate, untimed pass)
+        eng.profile(True)
+        for i in range(3):
+            eng.submit(0, x_dev[i % n_distinct], s_dev[i % n_distinct], beam_width=0, want_prob=True)
+            eng.collect(0)
+        stats = eng.profile_read()
+        eng.profile(False)
+        gemm = {"ms": 0.0, "launches": 0, "flops": 0.0}
+        for k, s in stats.items():
+            if k.startswith("conv_") or k.startswith("lstm_proj"):
+                gemm["ms"] += s["total_ms"]
+                gemm["launches"] += s["launches"]
+                gemm["flops"] += s["flops"]
+        per_kernel = {k: {"avg_ms": s["total_ms"] / s["launches"], "launches_per_batch": s["launches"] / 3.0,
+                          "tflops": (s["flops"] / (s["total_ms"] * 1e-3) / 1e12) if s["total_ms"] > 0 else 0.0,
+                          "gbps": (s["bytes"] / (s["total_ms"] * 1e-3) / 1e9) if s["total_ms"] > 0 else 0.0}
+                      for k, s in stats.items()}
+        achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": "gemm_f32_kernel (conv + LSTM-projection launches)", "bound": "mfma",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
+                    "flops_per_launch": gemm["flops"] / gemm["launches"]}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(spec, weights, xb, lb, eng.ratio, args.cpu_windows)
+        out = {
+            "metric": "kilobases/sec basecalled (DNA_default seg_len=400 batch=1100)",
+            "value": round(value, 2), "unit": "kbases/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DNA_default seg_len=400 jump=390 batch=1100 greedy, synthetic 4 kHz signal "
+                                   "(BASELINE.json configs[1])", "segment_len": SEG_LEN, "jump": JUMP,
+                       "batch": BATCH, "decode": "greedy", "weights": "seeded synthetic (exact checkpoint shapes)",
+                       "parallelism": "reads sharded per GPU, no collective", "slots_in_flight": 2},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "extra": {"windows_per_s": round(windows / dt, 1),
+                      "decoded_bases_per_s": round(decoded_bases[0] / dt, 1),
+                      "consensus_bases_per_s": round(consensus_bases[0] / dt, 1),
+                      "lstm_gemm_roofline_frac_whole_path": round(windows / dt * LSTM_GEMM_FLOP_PER_WINDOW / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                      "model_tflops_whole_path": round(windows / dt * MODEL_FLOP_PER_WINDOW / 1e12, 2),
+                      "kernels": per_kernel}}
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(spec, weights, xb, lb, ratio, n_windows):
+    """oracle/chiron_oracle.c (fp32 C restatement, OpenMP over windows) on this host's cores: the
+    'port' CPU baseline.  Bounded sample: a few windows per thread."""
+    from oracle import c_oracle
+    import chiron_amd as ca
+    threads = c_oracle.max_threads()
+    cores = os.cpu_count() or threads
+    threads = min(threads, cores)
+    n = n_windows if n_windows > 0 else max(threads * 2, 16)
+    n = min(n, xb.shape[0] * xb.shape[1])
+    x = xb.reshape(-1, SEG_LEN)[:n]
+    sl = ca.seq_len_for_engine(lb.reshape(-1)[:n], ratio)
+    blob = spec.pack(weights)
+    c_oracle.forward(x[:threads], sl[:threads], spec.to_dict(), blob, spec.output_len(SEG_LEN), threads)  # warm
+    t0 = time.perf_counter()
+    lg = c_oracle.forward(x, sl, spec.to_dict(), blob, spec.output_len(SEG_LEN), threads)
+    c_oracle.greedy(lg, sl)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * BASES_PER_WINDOW / 1000.0 / dt, 3), "unit": "kbases/s", "cores": threads,
+            "kind": "port", "sample": "%d windows of the same synthetic workload, oracle/chiron_oracle.c "
+            "(fp32, gcc -O3 AVX2, OpenMP over windows), %.1f s" % (n, dt)}
+
+
+if __name__ == "__main__":
+    main()

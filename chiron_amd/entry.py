@@ -1,0 +1,96 @@
+"""Command line (counterpart of chiron/entry.py): `python -m chiron_amd.entry call ...`.
+
+Keeps the reference's `chiron call` flags and presets (entry.py:19-47, :69-92); only inference is
+built (export/train are out of scope)."""
+import argparse
+import sys
+from os import path
+
+from . import __version__
+
+
+def set_paras(args, p):
+    """entry.py:53-60: explicit flags win over the preset."""
+    args.start = p["start"] if args.start is None else args.start
+    args.batch_size = p["batch_size"] if args.batch_size is None else args.batch_size
+    args.segment_len = p["segment_len"] if args.segment_len is None else args.segment_len
+    args.jump = p["jump"] if args.jump is None else args.jump
+    args.threads = p["threads"] if args.threads is None else args.threads
+    args.beam = p["beam"] if args.beam is None else args.beam
+    return args
+
+
+def resolve_preset(args):
+    """entry.py:20-32."""
+    if args.preset is None:
+        default_p = {"start": 0, "batch_size": 400, "segment_len": 500, "jump": 490, "threads": 0, "beam": 30}
+    elif args.preset == "dna-pre":
+        default_p = {"start": 0, "batch_size": 400, "segment_len": 400, "jump": 390, "threads": 0, "beam": 30}
+        if args.mode == "rna":
+            raise ValueError("Try to use the DNA preset parameter setting in RNA mode.")
+    elif args.preset == "rna-pre":
+        default_p = {"start": 0, "batch_size": 300, "segment_len": 2000, "jump": 1900, "threads": 0, "beam": 30}
+        if args.mode == "dna":
+            raise ValueError("Attempt to use the RNA preset parameter setting in DNA mode, enable RNA basecalling by --mode rna")
+    else:
+        raise ValueError("Unknown presetting %s undifiend" % (args.preset))
+    return set_paras(args, default_p)
+
+
+def evaluation(args):
+    """entry.py:19-47: extract fast5 -> <out>/raw, then basecall <out>/raw."""
+    from . import eval as chiron_eval
+    from .extract import extract
+    args = resolve_preset(args)
+    FLAGS = args
+    FLAGS.input_dir = FLAGS.input
+    FLAGS.output_dir = FLAGS.output
+    FLAGS.unit = False
+    FLAGS.recursive = True
+    FLAGS.polya = None
+    FLAGS.idname = False
+    FLAGS.delimiter = "\n"
+    args.reverse_fast5 = args.mode == "rna"
+    if path.isdir(FLAGS.input):
+        extract(FLAGS)
+        FLAGS.input = FLAGS.output + "/raw/"
+    return chiron_eval.run(args)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(prog="chiron", description="A deep neural network basecaller (MI355X engine).")
+    parser.add_argument("-v", "--version", action="version", version="chiron_amd version " + __version__)
+    subparsers = parser.add_subparsers(title="sub command", help="sub command help")
+    model_default_path = path.join(path.abspath(path.dirname(__file__)), "model", "DNA_default")
+    p = subparsers.add_parser("call", description="Perform basecalling", help="Perform basecalling.")
+    p.add_argument("-i", "--input", required=True, help="File path or Folder path to the fast5 file.")
+    p.add_argument("-o", "--output", required=True, help="Output folder path")
+    p.add_argument("-m", "--model", type=str, default=model_default_path, help="model folder path")
+    p.add_argument("-s", "--start", type=int, default=None, help="Start index of the signal file.")
+    p.add_argument("-b", "--batch_size", type=int, default=None, help="Batch size for run.")
+    p.add_argument("-l", "--segment_len", type=int, default=None, help="Segment length to be divided into.")
+    p.add_argument("-j", "--jump", type=int, default=None, help="Step size for segment")
+    p.add_argument("-t", "--threads", type=int, default=None, help="Host threads, 0 = all.")
+    p.add_argument("-e", "--extension", default="fastq", help="Output file type.")
+    p.add_argument("--beam", type=int, default=None, help="Beam width of the CTC beam search decoder, 0 = greedy.")
+    p.add_argument("--concise", action="store_true", help="Only write the result files.")
+    p.add_argument("--mode", default="dna", help="Output mode, dna or rna.")
+    p.add_argument("--test_number", default=None, type=int, help="Extract test_number reads, default all.")
+    p.add_argument("-p", "--preset", default=None, help="Preset evaluation parameters: dna-pre, rna-pre")
+    p.add_argument("--device", type=int, default=0, help="HIP device ordinal.")
+    p.add_argument("--synthetic-weights", dest="synthetic_weights", action="store_true",
+                   help="Use seeded synthetic weights when the model folder has no checkpoint data.")
+    p.set_defaults(func=evaluation)
+    return parser
+
+
+def main(arguments=None):
+    parser = build_parser()
+    args = parser.parse_args(sys.argv[1:] if arguments is None else arguments)
+    if hasattr(args, "func"):
+        return args.func(args)
+    parser.print_help()
+
+
+if __name__ == "__main__":
+    main()

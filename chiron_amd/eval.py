@@ -1,0 +1,344 @@
+"""Basecalling pipeline (counterpart of chiron/chiron_eval.py).
+
+TensorFlow's session / FIFOQueues / QueueRunner threads are replaced by one Engine per GPU with
+several batches in flight on HIP streams; the host keeps the reference's structure: cross-read
+batch packing (_worker_fn, chiron_eval.py:304-368), per-file regroup (evaluation, :383-446),
+consensus (:447-457) and the writers (:176-242).
+
+Deliberate divergences from HEAD, each listed in SURVEY.md appendix D:
+  Q3 regroup orders a read's pieces by within-file window index (HEAD's key shadowing scrambles
+     multi-batch reads); Q4 no debug prints; Q5 each file is parsed once; Q6 sorted file order.
+"""
+import os
+import sys
+import time
+from collections import namedtuple
+
+import numpy as np
+
+from . import assembly
+from . import model as model_mod
+from . import signal_io
+from .engine import Engine, SparseTensor, seq_len_for_engine
+from .unix_time import unix_time
+
+BASES = "ACGT"
+
+
+def sparse2dense(predict_val):
+    """chiron_eval.py:36-66: (decoded SparseTensors, log_prob) -> ragged reads + the row ids that
+    have a non-empty decode (rows with an empty decode vanish)."""
+    predict_read, uniq_list = [], []
+    for decode in predict_val[0]:
+        unique, pre_counts = np.unique(decode.indices[:, 0], return_counts=True)
+        uniq_list.append(unique)
+        pos = 0
+        reads = []
+        for c in pre_counts:
+            reads.append(decode.values[pos:pos + c])
+            pos += c
+        predict_read.append(reads)
+    return predict_read, uniq_list
+
+
+def slice_sparse_tensor(input_sp, start, end):
+    """chiron_eval.py:68-83."""
+    mask = np.logical_and(input_sp.indices[:, 0] >= start, input_sp.indices[:, 0] < end)
+    new_indices = input_sp.indices[mask] - [start, 0]
+    return SparseTensor(indices=new_indices, values=input_sp.values[mask],
+                        dense_shape=np.asarray([end - start, input_sp.dense_shape[1]]))
+
+
+def slice_ctc_decoding_result(input_decode, start, end):
+    """chiron_eval.py:85-98."""
+    return ([slice_sparse_tensor(d, start, end) for d in input_decode[0]], input_decode[1][start:end, :])
+
+
+def index2base(read):
+    """chiron_eval.py:100-113."""
+    return "".join(BASES[int(x)] for x in read)
+
+
+def get_assembler_kernal(jump, segment_len):
+    """chiron_eval.py:138-150."""
+    assembler = "simple"
+    if jump > 0.9 * segment_len:
+        assembler = "glue"
+    if jump >= segment_len:
+        assembler = "stick"
+    return assembler
+
+
+def qs(consensus, consensus_qs, output_standard="phred+33"):
+    """chiron_eval.py:152-174."""
+    sort_ind = np.argsort(consensus, axis=0)
+    L = consensus.shape[1]
+    cols = np.arange(L)[np.newaxis, :]
+    sorted_consensus = consensus[sort_ind, cols]
+    sorted_consensus_qs = consensus_qs[sort_ind, cols]
+    quality_score = 10 * (np.log10((sorted_consensus[3, :] + 1) / (sorted_consensus[2, :] + 1))) + \
+        sorted_consensus_qs[3, :] / sorted_consensus[3, :] / np.log(10)
+    if output_standard == "number":
+        return quality_score.astype(int)
+    elif output_standard == "phred+33":
+        return "".join(chr(x + 33) for x in quality_score.astype(int))
+
+
+def write_output(segments, consensus, time_list, file_pre, global_setting, concise=False, suffix="fasta",
+                 seg_q_score=None, q_score=None):
+    """chiron_eval.py:176-242: result/<pre>.<suffix>, segments/<pre>.<suffix>, meta/<pre>.meta."""
+    start_time, reading_time, basecall_time, assembly_time = time_list
+    result_folder = os.path.join(global_setting.output, "result")
+    seg_folder = os.path.join(global_setting.output, "segments")
+    meta_folder = os.path.join(global_setting.output, "meta")
+    for d in (result_folder,) + (() if concise else (seg_folder, meta_folder)):
+        os.makedirs(os.path.dirname(os.path.join(d, file_pre)), exist_ok=True)
+    path_con = os.path.join(result_folder, file_pre + "." + suffix)
+    if global_setting.mode == "rna":
+        consensus = consensus.replace("T", "U").replace("t", "u")
+    with open(path_con, "w+") as out_con:
+        if not concise:
+            with open(os.path.join(seg_folder, file_pre + "." + suffix), "w+") as out_f:
+                for indx, read in enumerate(segments):
+                    out_f.write(">{}{}\n{}\n".format(file_pre, str(indx), read))
+                    if (suffix == "fastq") and (seg_q_score is not None):
+                        out_f.write("@{}{}\n{}\n+\n{}\n".format(file_pre, str(indx), read, seg_q_score[indx]))
+        if (suffix == "fastq") and (q_score is not None):
+            out_con.write("@{}\n{}\n+\n{}\n".format(file_pre, consensus, q_score))
+        else:
+            out_con.write(">{}\n{}".format(file_pre, consensus))
+    if not concise:
+        with open(os.path.join(meta_folder, file_pre + ".meta"), "w+") as out_meta:
+            total_time = time.time() - start_time
+            output_time = total_time - assembly_time
+            assembly_time -= basecall_time
+            basecall_time -= reading_time
+            total_len = len(consensus)
+            total_time = time.time() - start_time
+            out_meta.write("# Reading Basecalling assembly output total rate(bp/s)\n")
+            out_meta.write("%5.3f %5.3f %5.3f %5.3f %5.3f %5.3f\n" % (
+                reading_time, basecall_time, assembly_time, output_time, total_time, total_len / total_time))
+            out_meta.write("# read_len batch_size segment_len jump start_pos\n")
+            out_meta.write("%d %d %d %d %d\n" % (total_len, global_setting.batch_size, global_setting.segment_len,
+                                                 global_setting.jump, global_setting.start))
+            out_meta.write("# input_name model_name\n")
+            out_meta.write("%s %s\n" % (global_setting.input, global_setting.model))
+
+
+# ------------------------------------------------------------------------------------------------
+# cross-read batch packing: the feed side (chiron_eval.py:304-368)
+# ------------------------------------------------------------------------------------------------
+Batch = namedtuple("Batch", "x seq_len fname index n_valid")
+
+
+class BatchPacker(object):
+    """Append the windows of successive reads until exactly `batch_size` rows are present
+    (chiron_eval.py:321-334).  Each row carries (file name, index of the chunk's first window within
+    its file) exactly as the reference tags them (:328-329).  The final partial batch is padded
+    by np.pad(mode='wrap') with tags -1 / '' (:352-360)."""
+
+    def __init__(self, batch_size, segment_len, ratio):
+        self.batch_size, self.segment_len, self.ratio = batch_size, segment_len, ratio
+        self._reset()
+
+    def _reset(self):
+        self.x, self.sl, self.idx, self.fn = [], [], [], []
+        self.n = 0
+
+    def add_read(self, name, event, event_length):
+        """yield full batches while consuming one read's windows"""
+        ds = signal_io.DataSet(event, event_length)
+        i = 0
+        if ds.reads_n == 0:
+            return
+        while ds.epochs_completed == 0:
+            cur, cur_len, _ = ds.next_batch(self.batch_size - self.n, shuffle=False)
+            n = len(cur)
+            self.x.append(cur)
+            self.sl.append(cur_len)
+            self.idx.append(np.full(n, i, dtype=np.int64))
+            self.fn.append(np.asarray([name] * n, dtype=object))
+            self.n += n
+            i += n
+            if self.n < self.batch_size:
+                continue
+            yield self._emit(self.n)
+
+    def _emit(self, n_valid):
+        x = np.concatenate(self.x, axis=0)
+        sl = np.concatenate(self.sl, axis=0)
+        idx = np.concatenate(self.idx, axis=0)
+        fn = np.concatenate(self.fn, axis=0)
+        if n_valid < self.batch_size:
+            pad = self.batch_size - n_valid
+            x = np.pad(x, ((0, pad), (0, 0)), mode="wrap")
+            sl = np.pad(sl, (0, pad), mode="wrap")
+            idx = np.pad(idx, (0, pad), mode="constant", constant_values=-1)
+            fn = np.concatenate([fn, np.asarray([""] * pad, dtype=object)])
+        b = Batch(np.ascontiguousarray(x, dtype=np.float32), seq_len_for_engine(sl, self.ratio), fn, idx, n_valid)
+        self._reset()
+        return b
+
+    def flush(self):
+        if self.n > 0:
+            return self._emit(self.n)
+        return None
+
+
+class ReadCollector(object):
+    """The drain side (chiron_eval.py:403-446): split each decoded batch into contiguous per-file runs,
+    re-index rows, and release a read once all of its windows have arrived, pieces ordered by the
+    within-file index of their first window (intended semantic)."""
+
+    def __init__(self):
+        self.val = {}
+
+    def expect(self, name, reads_n, meta):
+        self.val.setdefault(name, {"total": 0, "pieces": {}})
+        self.val[name]["reads_n"] = reads_n
+        self.val[name]["meta"] = meta
+
+    def add_batch(self, batch, result, want_qs):
+        """-> list of (name, reads [ragged int arrays], qs_list [n,1], meta) for completed reads"""
+        fnames = batch.fname
+        done = []
+        pos = 0
+        B = len(fnames)
+        predict_val = ([result.decoded], result.log_prob)
+        while pos < B:
+            fn = fnames[pos]
+            end = pos
+            while end < B and fnames[end] == fn:
+                end += 1
+            if fn != "":
+                first_idx = int(batch.index[pos])
+                sliced = slice_ctc_decoding_result(predict_val, pos, end)
+                rec = self.val.setdefault(fn, {"total": 0, "pieces": {}})
+                rec["pieces"][first_idx] = (sliced, result.prob_logits[pos:end])
+                rec["total"] += end - pos
+                if "reads_n" in rec and rec["total"] == rec["reads_n"]:
+                    done.append(self._finish(fn, want_qs))
+            pos = end
+        return done
+
+    def _finish(self, name, want_qs):
+        rec = self.val.pop(name)
+        reads = []
+        qs_list = np.empty((0, 1), dtype=float)
+        for i in sorted(rec["pieces"]):
+            predict_val, logits_prob = rec["pieces"][i]
+            predict_read, unique = sparse2dense(predict_val)
+            if want_qs:
+                qs_list = np.concatenate((qs_list, logits_prob[unique[0]]))
+            reads += predict_read[0]
+        return name, reads, qs_list, rec["meta"]
+
+
+def list_inputs(input_path, recursive):
+    """chiron_eval.py:277-293, sorted (Q6)."""
+    if os.path.isdir(input_path):
+        files = []
+        if recursive:
+            for dirpath, _, filenames in os.walk(input_path):
+                for fn in filenames:
+                    files.append(os.path.relpath(os.path.join(dirpath, fn), input_path))
+        else:
+            files = os.listdir(input_path)
+        return sorted(files), input_path
+    return [os.path.basename(input_path)], os.path.abspath(os.path.join(input_path, os.path.pardir))
+
+
+def finish_read(name, reads, qs_list, FLAGS, t_start, reading_time):
+    """chiron_eval.py:446-462: bases, consensus vote, quality string, writers."""
+    file_pre = os.path.splitext(name)[0]
+    basecall_time = time.time() - t_start
+    bpreads = [index2base(read) for read in reads]
+    js_ratio = FLAGS.jump / FLAGS.segment_len
+    kernal = get_assembler_kernal(FLAGS.jump, FLAGS.segment_len)
+    qs_string = None
+    if FLAGS.extension == "fastq":
+        consensus, qs_consensus = assembly.simple_assembly_qs(bpreads, qs_list, js_ratio, kernal=kernal)
+        qs_string = qs(consensus, qs_consensus)
+    else:
+        consensus = assembly.simple_assembly(bpreads, js_ratio, kernal=kernal)
+    c_bpread = index2base(np.argmax(consensus, axis=0))
+    assembly_time = time.time() - t_start
+    write_output(bpreads, c_bpread, [t_start, reading_time, basecall_time, assembly_time], file_pre,
+                 concise=FLAGS.concise, suffix=FLAGS.extension, q_score=qs_string, global_setting=FLAGS)
+    return c_bpread
+
+
+def evaluation(FLAGS, engine=None, file_list=None):
+    """chiron_eval.py:378-463 on one GPU.  `file_list` restricts the reads this process handles
+    (per-read sharding across GPUs)."""
+    own_engine = engine is None
+    if own_engine:
+        spec, weights, _ = model_mod.load_model(FLAGS.model, allow_synthetic=getattr(FLAGS, "synthetic_weights", False))
+        engine = Engine(spec, weights, max_batch=FLAGS.batch_size, segment_len=FLAGS.segment_len,
+                        device_id=getattr(FLAGS, "device", 0), n_slots=2, max_beam=FLAGS.beam)
+    files, file_dir = list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
+    if file_list is not None:
+        files = [f for f in files if f in set(file_list)]
+    for sub in ("segments", "result", "meta"):
+        os.makedirs(os.path.join(FLAGS.output, sub), exist_ok=True)
+    want_qs = FLAGS.extension == "fastq"
+    packer = BatchPacker(FLAGS.batch_size, FLAGS.segment_len, engine.ratio)
+    collector = ReadCollector()
+    inflight = [None] * engine.n_slots
+    results = {}
+    step = [0]
+
+    def drain(slot):
+        if inflight[slot] is None:
+            return
+        batch = inflight[slot]
+        res = engine.collect(slot)
+        inflight[slot] = None
+        for name, reads, qs_list, meta in collector.add_batch(batch, res, want_qs):
+            results[name] = finish_read(name, reads, qs_list, FLAGS, meta[0], meta[1])
+
+    def launch(batch):
+        slot = step[0] % engine.n_slots
+        step[0] += 1
+        drain(slot)
+        engine.submit(slot, batch.x, batch.seq_len, beam_width=FLAGS.beam, want_prob=want_qs)
+        inflight[slot] = batch
+
+    for name in files:
+        if (not name.endswith(".signal")) and (not name.endswith(".fast5")):
+            continue
+        t0 = time.time()
+        ds = signal_io.read_data_for_eval(os.path.join(file_dir, name), FLAGS.start, seg_length=FLAGS.segment_len,
+                                          step=FLAGS.jump, reverse_fast5=getattr(FLAGS, "reverse_fast5", False))
+        collector.expect(name, ds.reads_n, (t0, time.time() - t0))
+        if ds.reads_n == 0:
+            results[name] = finish_read(name, [], np.empty((0, 1)), FLAGS, t0, time.time() - t0)
+            collector.val.pop(name, None)
+            continue
+        for batch in packer.add_read(name, ds.event, ds.event_length):
+            launch(batch)
+    last = packer.flush()
+    if last is not None:
+        launch(last)
+    for slot in range(engine.n_slots):
+        drain((step[0] + slot) % engine.n_slots)
+    if own_engine:
+        engine.close()
+    return results
+
+
+def run(args):
+    """chiron_eval.py:525-544."""
+    FLAGS = args
+    print("The result will be written to %s" % (FLAGS.output))
+    os.makedirs(FLAGS.output, exist_ok=True)
+    time_dict = unix_time(evaluation, FLAGS)
+    print("Real time:%5.3f Systime:%5.3f Usertime:%5.3f" % (time_dict["real"], time_dict["sys"], time_dict["user"]))
+    meta_folder = os.path.join(FLAGS.output, "meta")
+    os.makedirs(meta_folder, exist_ok=True)
+    file_pre = "all" if os.path.isdir(FLAGS.input) else os.path.splitext(os.path.basename(FLAGS.input))[0]
+    with open(os.path.join(meta_folder, file_pre + ".meta"), "a+") as out_meta:
+        out_meta.write("# Wall_time Sys_time User_time Cpu_time\n")
+        out_meta.write("%5.3f %5.3f %5.3f %5.3f\n" % (time_dict["real"], time_dict["sys"], time_dict["user"],
+                                                      time_dict["sys"] + time_dict["user"]))
+    return time_dict

@@ -1,0 +1,92 @@
+"""fast5 -> <out>/raw/<name>.signal (counterpart of chiron/utils/extract_sig_ref.py).
+
+Uses the package's own minimal HDF5 reader (fast5.py); h5py is not required.  Unreadable reads are
+logged to <out>/log/extract.log and skipped (extract_sig_ref.py:97-117)."""
+import logging
+import os
+from multiprocessing import Pool, cpu_count
+
+import numpy as np
+
+logger = logging.getLogger(name="chiron_call")
+
+
+def set_logger(log_file):
+    hd = logging.FileHandler(log_file)
+    hd.setFormatter(logging.Formatter("%(asctime)s %(levelname)s %(message)s"))
+    logger.addHandler(hd)
+    logger.propagate = False
+    logger.setLevel(logging.INFO)
+
+
+def extract_file(path, mode="dna", unit=False):
+    """extract_sig_ref.py:149-175 / :178-193 -> list of (suffix, raw_signal, reference, read_id)."""
+    from . import fast5
+    out = []
+    for rec in fast5.read_fast5(path):
+        raw = np.asarray(rec["signal"])
+        if unit and rec.get("channel") is not None:
+            ch = rec["channel"]            # (raw+offset)*range/digitisation, extract_sig_ref.py:153-158
+            raw = (raw + float(ch["offset"])) * float(ch["range"]) / float(ch["digitisation"])
+        if mode == "rna":
+            raw = raw[::-1]                # extract_sig_ref.py:165
+        out.append((rec.get("suffix", ""), raw, rec.get("fastq", ""), rec.get("read_id", "")))
+    return out
+
+
+def _wrapper(args):
+    full, FLAGS = args
+    file_n = os.path.basename(full)
+    stem = os.path.splitext(file_n)[0]
+    try:
+        recs = extract_file(full, FLAGS.mode, getattr(FLAGS, "unit", False))
+        if not recs:
+            raise ValueError("Fail in extracting raw signal.")
+    except Exception as e:  # noqa: BLE001 -- skip-and-log like the reference
+        logger.error("Cannot extract file %s. %s" % (full, e))
+        return 0
+    n = 0
+    for suffix, raw, reference, read_id in recs:
+        if len(raw) == 0:
+            logger.error("Cannot extract file %s. Got empty raw signal" % full)
+            continue
+        name = read_id if getattr(FLAGS, "idname", False) else stem + suffix
+        with open(os.path.join(FLAGS.raw_folder, name + ".signal"), "w+") as f:
+            f.write(FLAGS.delimiter.join([str(v) for v in raw.tolist()]))     # extract_sig_ref.py:122-123
+        if len(reference) > 0:
+            head = "@%s\n" % stem
+            with open(os.path.join(FLAGS.ref_folder, stem + "_ref.fastq"), "w+") as f:
+                f.write(head + "\n".join(reference.split("\n")[1:]))
+        n += 1
+    return n
+
+
+def extract(FLAGS):
+    """extract_sig_ref.py:31-90."""
+    root_folder, out_folder = FLAGS.input_dir, FLAGS.output_dir
+    if not os.path.isdir(root_folder):
+        raise IOError("Input directory does not found.")
+    os.makedirs(out_folder, exist_ok=True)
+    FLAGS.raw_folder = os.path.abspath(os.path.join(out_folder, "raw"))
+    FLAGS.ref_folder = os.path.abspath(os.path.join(out_folder, "reference"))
+    FLAGS.log_folder = os.path.abspath(os.path.join(out_folder, "log"))
+    for d in (FLAGS.raw_folder, FLAGS.ref_folder, FLAGS.log_folder):
+        os.makedirs(d, exist_ok=True)
+    set_logger(os.path.join(FLAGS.log_folder, "extract.log"))
+    threads = FLAGS.threads if getattr(FLAGS, "threads", 0) else cpu_count()
+    files = []
+    for dirpath, _, filenames in os.walk(root_folder):
+        for fn in sorted(filenames):
+            if fn.endswith("fast5"):
+                files.append(os.path.join(dirpath, fn))
+        if not getattr(FLAGS, "recursive", True):
+            break
+    files.sort()
+    if getattr(FLAGS, "test_number", None):
+        files = files[:FLAGS.test_number]
+    if threads > 1 and len(files) > 1:
+        with Pool(min(threads, len(files))) as pool:
+            counts = pool.map(_wrapper, [(f, FLAGS) for f in files])
+    else:
+        counts = [_wrapper((f, FLAGS)) for f in files]
+    return int(sum(counts))

@@ -1,0 +1,269 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) -- plain C / fp32 restatement of the reference
+ * forward pass + greedy CTC, used (a) as a second, faster checker next to the numpy oracle and
+ * (b) as the timed CPU baseline ("port") of bench.py.  Never linked into the product library.
+ *
+ * Follows: chiron/cnn.py:15-83 conv_layer, :125-163 batchnorm (population branch), :234-262
+ * residual_layer, :334-371 getcnnfeature; chiron/rnn.py:20-97 / :99-174 (TF LSTMCell under
+ * dynamic_rnn with sequence_length); rnn.py:72-96 FC head;
+ * tf.nn.ctc_greedy_decoder(merge_repeated=True) (chiron_eval.py:485-487, appendix A.4).
+ * PARITY UNPINNED against TensorFlow itself (TF 1.15 and the trained weights are unavailable).
+ *
+ * Weight blob order = include/chiron_amd.h.  desc = {n_blocks, (in,out,k,stride,i_bn)*n_blocks,
+ * rnn_kind, layers, hidden, classes, bn_mode}.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BN_EPS 1e-5f
+
+static void same_pad(int w, int k, int s, int* out, int* left) {
+  *out = (w + s - 1) / s;
+  int tot = (*out - 1) * s + k - w;
+  if (tot < 0) tot = 0;
+  *left = tot / 2;
+}
+
+/* in [W][ci], w [k][ci][co] (TF HWIO, H squeezed), out [Tout][co] */
+static void conv1d(const float* in, int W, int ci, const float* w, int k, int co, int stride, float* out, int* tout) {
+  int T, left;
+  same_pad(W, k, stride, &T, &left);
+  *tout = T;
+  memset(out, 0, sizeof(float) * (size_t)T * co);
+  for (int t = 0; t < T; ++t) {
+    float* o = out + (size_t)t * co;
+    for (int tap = 0; tap < k; ++tap) {
+      const int it = t * stride + tap - left;
+      if (it < 0 || it >= W) continue;
+      const float* x = in + (size_t)it * ci;
+      const float* wt = w + (size_t)tap * ci * co;
+      for (int c = 0; c < ci; ++c) {
+        const float xv = x[c];
+        const float* wr = wt + (size_t)c * co;
+        for (int n = 0; n < co; ++n) o[n] += xv * wr[n];
+      }
+    }
+  }
+}
+
+static void bn_relu(float* x, int T, int co, const float* bn /* scale,offset,mean,var */, int relu) {
+  for (int n = 0; n < co; ++n) {
+    const float inv = (1.0f / sqrtf(bn[3 * co + n] + BN_EPS)) * bn[n];
+    const float sh = bn[co + n] - bn[2 * co + n] * inv;
+    for (int t = 0; t < T; ++t) {
+      float v = x[(size_t)t * co + n] * inv + sh;
+      if (relu && v < 0.f) v = 0.f;
+      x[(size_t)t * co + n] = v;
+    }
+  }
+}
+
+static float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+/* one direction of one LSTM layer for one row. x [T][in], out [T][H] (row stride ldo), kernel [(in+H)][4H] */
+static void lstm_dir(const float* x, int T, int in, int len, const float* kernel, const float* bias, int H, int reverse,
+                     float* out, int ldo, float* z /* scratch 4H */) {
+  float* h = (float*)calloc((size_t)2 * H, sizeof(float));
+  float* c = h + H;
+  for (int t = 0; t < T; ++t) memset(out + (size_t)t * ldo, 0, sizeof(float) * H);
+  if (len > T) len = T;
+  for (int s = 0; s < len; ++s) {
+    const int t = reverse ? len - 1 - s : s;
+    const float* xt = x + (size_t)t * in;
+    for (int n = 0; n < 4 * H; ++n) z[n] = bias[n];
+    for (int k = 0; k < in; ++k) {
+      const float v = xt[k];
+      const float* wr = kernel + (size_t)k * 4 * H;
+      for (int n = 0; n < 4 * H; ++n) z[n] += v * wr[n];
+    }
+    for (int k = 0; k < H; ++k) {
+      const float v = h[k];
+      const float* wr = kernel + (size_t)(in + k) * 4 * H;
+      for (int n = 0; n < 4 * H; ++n) z[n] += v * wr[n];
+    }
+    float* o = out + (size_t)t * ldo;
+    for (int u = 0; u < H; ++u) {
+      const float gi = z[u], gj = z[H + u], gf = z[2 * H + u], go = z[3 * H + u];
+      const float cn = sigmoidf_(gf + 1.0f) * c[u] + sigmoidf_(gi) * tanhf(gj);
+      const float hn = sigmoidf_(go) * tanhf(cn);
+      c[u] = cn;
+      h[u] = hn;
+      o[u] = hn;
+    }
+  }
+  free(h);
+}
+
+static size_t block_floats(const int* b) {
+  const size_t ci = b[0], co = b[1], k = b[2];
+  return ci * co + (b[4] ? 4 * co : 0) + ci * co + 4 * co + k * co * co + 4 * co + co * co + 4 * co;
+}
+
+/* logits [B][T][K]; returns T (or <0 on error) */
+int chiron_oracle_forward(const int* desc, const float* w, const float* x, const int* seq_len, int B, int L,
+                          float* logits, int threads) {
+  const int nb = desc[0];
+  const int* blocks = desc + 1;
+  const int rnn_kind = desc[1 + 5 * nb], layers = desc[2 + 5 * nb], H = desc[3 + 5 * nb], K = desc[4 + 5 * nb];
+  const int bn_mode = desc[5 + 5 * nb];
+  if (bn_mode != 0) return -1;
+  int T = L, Tmax = L, C = 1;
+  for (int i = 0; i < nb; ++i) {
+    int left;
+    same_pad(T, blocks[5 * i + 2], blocks[5 * i + 3], &T, &left);
+    if (blocks[5 * i + 1] > C) C = blocks[5 * i + 1];
+  }
+  const float* wl = w;
+  for (int i = 0; i < nb; ++i) wl += block_floats(blocks + 5 * i);
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b) {
+    const size_t act = (size_t)Tmax * C;
+    float* cur = (float*)malloc(sizeof(float) * act * 5);
+    float *b1 = cur + act, *a = cur + 2 * act, *bb = cur + 3 * act, *cc = cur + 4 * act;
+    float* zs = (float*)malloc(sizeof(float) * 4 * H);
+    for (int t = 0; t < L; ++t) cur[t] = x[(size_t)b * L + t];
+    int W = L, ci = 1;
+    const float* p = w;
+    for (int i = 0; i < nb; ++i) {
+      const int co = blocks[5 * i + 1], k = blocks[5 * i + 2], s = blocks[5 * i + 3], ibn = blocks[5 * i + 4];
+      int t1, t2, t3, t4;
+      conv1d(cur, W, ci, p, 1, co, s, b1, &t1);
+      p += (size_t)ci * co;
+      if (ibn) {
+        bn_relu(b1, t1, co, p, 0);
+        p += 4 * co;
+      }
+      conv1d(cur, W, ci, p, 1, co, 1, a, &t2);
+      p += (size_t)ci * co;
+      bn_relu(a, t2, co, p, 1);
+      p += 4 * co;
+      conv1d(a, t2, co, p, k, co, s, bb, &t3);
+      p += (size_t)k * co * co;
+      bn_relu(bb, t3, co, p, 1);
+      p += 4 * co;
+      conv1d(bb, t3, co, p, 1, co, 1, cc, &t4);
+      p += (size_t)co * co;
+      bn_relu(cc, t4, co, p, 0);
+      p += 4 * co;
+      for (size_t j = 0; j < (size_t)t4 * co; ++j) {
+        const float v = b1[j] + cc[j];
+        cur[j] = v > 0.f ? v : 0.f;
+      }
+      W = t4;
+      ci = co;
+    }
+    /* RNN: cur [T][C] -> lasth [T][2H] */
+    int len = seq_len[b];
+    if (len < 0) len = 0;
+    float* in = cur;
+    int in_w = ci;
+    float* o0 = a;
+    float* o1 = bb;
+    const float* q = wl;
+    if (rnn_kind == 0) {
+      for (int l = 0; l < layers; ++l) {
+        float* out = (l & 1) ? o1 : o0;
+        for (int d = 0; d < 2; ++d) {
+          const float* kern = q;
+          q += (size_t)(in_w + H) * 4 * H;
+          const float* bias = q;
+          q += 4 * H;
+          lstm_dir(in, T, in_w, len, kern, bias, H, d, out + d * H, 2 * H, zs);
+        }
+        in = out;
+        in_w = 2 * H;
+      }
+    } else {
+      /* MultiRNNCell: fw stack and bw stack; layer l>0 input = own direction's previous output [T][H] */
+      float* outs[2] = {o0, o1};
+      float* fin = cc; /* final [T][2H] */
+      const float* kq[8][2];
+      const float* bq[8][2];
+      int iw = in_w;
+      for (int l = 0; l < layers; ++l) {
+        for (int d = 0; d < 2; ++d) {
+          kq[l][d] = q;
+          q += (size_t)(iw + H) * 4 * H;
+          bq[l][d] = q;
+          q += 4 * H;
+        }
+        iw = H;
+      }
+      for (int d = 0; d < 2; ++d) {
+        const float* src = cur;
+        int sw = in_w;
+        for (int l = 0; l < layers; ++l) {
+          float* dst = (l == layers - 1) ? fin + d * H : outs[l & 1];
+          const int ldo = (l == layers - 1) ? 2 * H : H;
+          lstm_dir(src, T, sw, len, kq[l][d], bq[l][d], H, d, dst, ldo, zs);
+          src = dst;
+          sw = H;
+        }
+      }
+      in = fin;
+    }
+    /* FC head */
+    const float* fw = q;
+    const float* fb = q + 2 * H;
+    const float* wc = fb + H;
+    const float* bc = wc + (size_t)H * K;
+    for (int t = 0; t < T; ++t) {
+      float* lg = logits + ((size_t)b * T + t) * K;
+      for (int k = 0; k < K; ++k) lg[k] = bc[k];
+      for (int u = 0; u < H; ++u) {
+        const float v = in[(size_t)t * 2 * H + u] * fw[u] + in[(size_t)t * 2 * H + H + u] * fw[H + u] + fb[u];
+        for (int k = 0; k < K; ++k) lg[k] += v * wc[(size_t)u * K + k];
+      }
+    }
+    free(zs);
+    free(cur);
+  }
+  return T;
+}
+
+/* greedy CTC: labels [B][T] (first count[b] valid), neg_sum_logits [B], path_prob [B] */
+void chiron_oracle_greedy(const float* logits, const int* seq_len, int B, int T, int K, unsigned char* labels,
+                          int* count, float* neg_sum, float* path_prob) {
+  for (int b = 0; b < B; ++b) {
+    int prev = -1, n = 0;
+    float acc = 0.f, diff = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float* lg = logits + ((size_t)b * T + t) * K;
+      int k = 0;
+      float m1 = lg[0], m2 = -INFINITY;
+      for (int j = 1; j < K; ++j) {
+        if (lg[j] > m1) {
+          m2 = m1;
+          m1 = lg[j];
+          k = j;
+        } else if (lg[j] > m2) {
+          m2 = lg[j];
+        }
+      }
+      diff += m1 - m2;
+      if (t < seq_len[b]) {
+        acc += -m1;
+        if (k != K - 1 && k != prev) labels[(size_t)b * T + n++] = (unsigned char)k;
+        prev = k;
+      }
+    }
+    count[b] = n;
+    neg_sum[b] = acc;
+    path_prob[b] = diff / (float)T;
+  }
+}
+
+int chiron_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

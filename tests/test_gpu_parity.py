@@ -1,0 +1,205 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against the oracle.
+
+Tolerances (north_star): pre-CTC logits within 1e-4 (fp32 device vs float64 numpy restatement);
+integer work (greedy decode, SparseTensor construction) bit-exact on identical logits."""
+import os
+
+import numpy as np
+import pytest
+
+import chiron_amd as ca
+from chiron_amd import _lib
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _windows(n_samples, L, jump, seed):
+    from chiron_amd import signal_io
+    sig = ca.synthetic_signal(1, n_samples, seed=seed)[0]
+    return signal_io.window_signal(sig, 0, jump, L)
+
+
+def _check_decode(res, logits, sl, B):
+    from oracle import ctc_oracle
+    rows, nsl = ctc_oracle.greedy_decode(logits, sl)
+    idx, val, shape = ctc_oracle.rows_to_sparse(rows, B)
+    assert np.array_equal(res.decoded.indices, idx)
+    assert np.array_equal(res.decoded.values, val)
+    assert np.array_equal(res.decoded.dense_shape, shape)
+    np.testing.assert_allclose(res.log_prob, nsl, rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(res.prob_logits, ctc_oracle.path_prob(logits), rtol=1e-5, atol=1e-5)
+    return rows
+
+
+@pytest.fixture(scope="module")
+def dna(built):
+    spec = ca.dna_default_spec()
+    return spec, ca.synthetic_weights(spec, seed=21)
+
+
+@pytest.fixture(scope="module")
+def rna(built):
+    spec = ca.rna_default_spec()
+    return spec, ca.synthetic_weights(spec, seed=22)
+
+
+def test_dna_logits_and_decode_small(dna):
+    from oracle import nn_oracle, c_oracle
+    spec, w = dna
+    L = 400
+    x, ln = _windows(390 * 18 + 77, L, 390, seed=5)          # 19 windows, last one 77 samples
+    B = x.shape[0]
+    with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
+        assert eng.T == 400 and eng.ratio == 1.0
+        sl = ca.seq_len_for_engine(ln, eng.ratio)
+        res = eng.infer(x, sl, want_prob=True, want_logits=True)
+    ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+    err = np.abs(res.logits.astype(np.float64) - ref).max()
+    assert err < TOL, err
+    cref = c_oracle.forward(x, sl, spec.to_dict(), spec.pack(w), 400)
+    assert np.abs(res.logits - cref).max() < TOL
+    rows = _check_decode(res, res.logits, sl, B)
+    # base strings equal the oracle's wherever the argmax margin exceeds the logit error
+    from oracle import ctc_oracle
+    orows, _ = ctc_oracle.greedy_decode(ref, sl)
+    s = np.sort(ref, axis=-1)
+    margin = (s[..., -1] - s[..., -2])
+    safe = np.asarray([margin[b, :sl[b]].min() > 10 * err if sl[b] else True for b in range(B)])
+    assert safe.sum() >= B // 2
+    for b in np.nonzero(safe)[0]:
+        assert rows[b] == orows[b]
+
+
+def test_rna_topology_stride5_multirnn(rna):
+    from oracle import nn_oracle
+    spec, w = rna
+    L = 500
+    x, ln = _windows(490 * 10 + 123, L, 490, seed=6)
+    B = x.shape[0]
+    with ca.Engine(spec, w, max_batch=B + 3, segment_len=L) as eng:
+        assert eng.T == 100 and eng.ratio == 5.0
+        sl = ca.seq_len_for_engine(ln, eng.ratio)          # round half even of len/5
+        res = eng.infer(x, sl, want_prob=True, want_logits=True)
+    ref, ratio = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+    assert ratio == 5.0
+    err = np.abs(res.logits.astype(np.float64) - ref).max()
+    assert err < TOL, err
+    _check_decode(res, res.logits, sl, B)
+
+
+def test_edge_cases_ragged_zero_and_single(dna):
+    from oracle import nn_oracle
+    spec, w = dna
+    L = 400
+    rng = np.random.RandomState(0)
+    B = 21                                                     # not a multiple of 16
+    x = ca.synthetic_signal(1, B * L, seed=9)[0].reshape(B, L)
+    sl = rng.randint(0, 401, size=B).astype(np.int32)
+    sl[:4] = [0, 1, 400, 399]
+    for b in range(B):
+        x[b, sl[b]:] = 0                                       # zero padded tails as the windower makes them
+    with ca.Engine(spec, w, max_batch=64, segment_len=L) as eng:
+        res = eng.infer(x, sl, want_prob=True, want_logits=True)
+        ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+        assert np.abs(res.logits.astype(np.float64) - ref).max() < TOL
+        _check_decode(res, res.logits, sl, B)
+        assert res.decoded.dense_shape[0] == B
+        # batch of one
+        r1 = eng.infer(x[2:3], sl[2:3], want_logits=True)
+        assert np.array_equal(r1.logits[0], res.logits[2])
+        # determinism: same input twice, and on every slot
+        r2 = eng.infer(x, sl, want_prob=True, want_logits=True)
+        assert np.array_equal(r2.logits, res.logits) and np.array_equal(r2.decoded.values, res.decoded.values)
+
+
+def test_errors_through_the_abi(dna):
+    spec, w = dna
+    with ca.Engine(spec, w, max_batch=8, segment_len=400) as eng:
+        x = np.zeros((9, 400), np.float32)
+        with pytest.raises(_lib.ChironError) as ei:
+            eng.infer(x, np.zeros(9, np.int32))
+        assert ei.value.status == _lib.ERR_OVERFLOW
+        with pytest.raises(_lib.ChironError) as ei:
+            eng.collect(0)
+        assert ei.value.status == _lib.ERR_STATE
+        with pytest.raises(ValueError):
+            eng.infer(np.zeros((2, 399), np.float32), np.zeros(2, np.int32))
+        with pytest.raises(_lib.ChironError) as ei:
+            eng.infer(np.zeros((2, 400), np.float32), np.zeros(2, np.int32), beam_width=5)   # max_beam=0 at create
+        assert ei.value.status == _lib.ERR_OVERFLOW
+
+
+def test_full_batch_1100_properties(dna):
+    """BASELINE configs[1] size: properties that do not need the oracle at full scale, plus the C oracle
+    on a sample of rows."""
+    import torch
+    from oracle import c_oracle
+    spec, w = dna
+    L, B = 400, 1100
+    x, ln = _windows(390 * (B - 1) + 200, L, 390, seed=12)
+    assert x.shape[0] == B
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=2) as eng:
+        sl = ca.seq_len_for_engine(ln, eng.ratio)
+        res = eng.infer(x, sl, want_prob=True, want_logits=True)
+        _check_decode(res, res.logits, sl, B)
+        assert np.isfinite(res.logits).all()
+        # (a) rows are independent (population BN): a permuted batch gives bit-identical rows
+        perm = np.random.RandomState(1).permutation(B)
+        rp = eng.infer(x[perm], sl[perm], want_logits=True, slot=1)
+        assert np.array_equal(rp.logits, res.logits[perm])
+        # (b) device-resident inputs (torch tensors) give the same answer as host buffers
+        xd = torch.from_numpy(x).cuda()
+        sd = torch.from_numpy(sl).cuda()
+        torch.cuda.synchronize()
+        rd = eng.infer(xd, sd, want_prob=True, want_logits=True)
+        assert np.array_equal(rd.logits, res.logits) and np.array_equal(rd.decoded.indices, res.decoded.indices)
+        # (c) two slots in flight do not disturb each other
+        eng.submit(0, x, sl, want_logits=True)
+        eng.submit(1, x[perm], sl[perm], want_logits=True)
+        a, b = eng.collect(0), eng.collect(1)
+        assert np.array_equal(a.logits, res.logits) and np.array_equal(b.logits, rp.logits)
+    # (d) oracle on a sample of rows, including the ragged last window
+    rows = np.concatenate([np.arange(0, B, 37), [B - 1]])
+    cref = c_oracle.forward(x[rows], sl[rows], spec.to_dict(), spec.pack(w), 400)
+    assert np.abs(res.logits[rows] - cref).max() < TOL
+
+
+def test_pipeline_end_to_end_on_example_signal(dna, tmp_path):
+    """chiron_eval-equivalent run on the reference's example raw signal (read1, 161 windows) with a batch
+    size that forces several batches and a wrap-padded tail; FASTQ/segments/meta are written, and the
+    consensus equals the Python pipeline fed with the oracle decode of the device logits."""
+    import shutil
+    from chiron_amd import eval as ce, assembly, signal_io
+    from oracle import ctc_oracle
+    spec, w = dna
+    inp = tmp_path / "raw"
+    inp.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "example_dna", "raw", "read1.signal"), str(inp / "read1.signal"))
+    (inp / "tiny.signal").write_text("500\n510\n490")
+    (inp / "notes.txt").write_text("ignored")
+
+    class F(object):
+        input, output, model = str(inp), str(tmp_path / "out"), "synthetic"
+        start, batch_size, segment_len, jump, beam = 0, 50, 400, 390, 0
+        extension, concise, mode, recursive = "fastq", False, "dna", True
+    with ca.Engine(spec, w, max_batch=50, segment_len=400, n_slots=2) as eng:
+        out = ce.evaluation(F, engine=eng)
+        ds = signal_io.read_data_for_eval(str(inp / "read1.signal"), 0, 390, 400)
+        logits = np.concatenate([eng.infer(ds.event[i:i + 50], ca.seq_len_for_engine(ds.event_length[i:i + 50], 1.0),
+                                           want_logits=True).logits for i in range(0, 161, 50)])
+    assert set(out) == {"read1.signal", "tiny.signal"}
+    rows, _ = ctc_oracle.greedy_decode(logits, ds.event_length)
+    pp = ctc_oracle.path_prob(logits)
+    keep = [i for i, r in enumerate(rows) if len(r)]
+    bp = [ce.index2base(rows[i]) for i in keep]
+    cons, cqs = assembly.simple_assembly_qs(bp, pp[keep], 390 / 400, kernal="glue")
+    want = ce.index2base(np.argmax(cons, axis=0))
+    assert out["read1.signal"] == want and len(want) > 0
+    fq = open(os.path.join(F.output, "result", "read1.fastq")).read().split("\n")
+    assert fq[0] == "@read1" and fq[1] == want and fq[2] == "+" and len(fq[3]) == len(want)
+    seg = open(os.path.join(F.output, "segments", "read1.fastq")).read().split("\n")
+    assert seg[0] == ">read10" and seg[1] == bp[0] and len(seg) == 2 * len(bp) + 1
+    assert os.path.exists(os.path.join(F.output, "meta", "read1.meta"))
+    assert open(os.path.join(F.output, "result", "tiny.fastq")).read().startswith("@tiny\n")

@@ -1,0 +1,239 @@
+"""CPU: the host-side pipeline functions against golden vectors captured from the reference's own
+Python functions (tests/golden/make_golden.py) and against the reference's checked-in example
+outputs.  Rows refer to SURVEY.md section 8(a)."""
+import os
+
+import numpy as np
+import pytest
+
+from chiron_amd import assembly, entry, signal_io
+from chiron_amd import eval as ce
+from conftest import GOLDEN
+
+EX = os.path.join(GOLDEN, "example_dna")
+SIG1 = os.path.join(EX, "raw", "read1.signal")
+
+
+def test_read_signal_H2(golden):
+    g = golden["read_signal_read1"]
+    sig = signal_io.read_signal(SIG1)
+    assert sig.dtype == np.float32 and len(sig) == g["len"] == 62461
+    assert sig[:16].tolist() == g["head"] and sig[-8:].tolist() == g["tail"]
+    assert float(np.sum(sig.astype(np.float64))) == g["sum"]
+
+
+@pytest.mark.parametrize("key", ["0_390_400", "0_30_400", "1000_390_400", "0_490_500", "61000_400_400"])
+def test_read_data_for_eval_H3(golden, key):
+    g = golden["read_data_for_eval_read1"][key]
+    start, step, seg = map(int, key.split("_"))
+    ds = signal_io.read_data_for_eval(SIG1, start, step, seg)
+    ev, ln = ds.event, ds.event_length
+    assert ds.reads_n == g["n"] == g["reads_n"]
+    assert ln[:3].tolist() == g["lengths_head"] and ln[-4:].tolist() == g["lengths_tail"]
+    assert ev[0][:6].tolist() == g["first_head"]
+    assert ev[-1][:8].tolist() + ev[-1][-4:].tolist() == g["last"]
+    assert int(np.count_nonzero(ev[-1])) == g["last_nonzero"]
+    chk = float(sum(float(np.sum(e.astype(np.float64)) * (i % 7 + 1)) for i, e in enumerate(ev)))
+    assert chk == g["checksum"]
+
+
+def test_read_data_for_eval_rejects_other_suffix():
+    with pytest.raises(TypeError):
+        signal_io.read_data_for_eval("foo.txt")
+
+
+def test_empty_and_short_signals(tmp_path):
+    p = tmp_path / "e.signal"
+    p.write_text("")
+    ds = signal_io.read_data_for_eval(str(p), 0, 390, 400)
+    assert ds.reads_n == 0
+    p.write_text("5 6\n7")
+    ds = signal_io.read_data_for_eval(str(p), 0, 390, 400)
+    assert ds.reads_n == 1 and ds.event_length.tolist() == [3] and ds.event[0, :4].tolist() == [5, 6, 7, 0]
+
+
+def test_next_batch_H4():
+    ev = np.arange(10 * 4, dtype=np.float32).reshape(10, 4)
+    ds = signal_io.DataSet(ev, np.full(10, 4))
+    x, l, _ = ds.next_batch(4)
+    assert x.shape == (4, 4) and ds.epochs_completed == 0
+    x, l, _ = ds.next_batch(4)
+    assert ds.epochs_completed == 0
+    x, l, _ = ds.next_batch(4)
+    assert x.shape == (2, 4) and ds.epochs_completed == 1 and l.dtype == np.int32
+    ds = signal_io.DataSet(ev, np.full(10, 4))
+    x, _, _ = ds.next_batch(10)                    # exactly the remainder also completes the epoch
+    assert x.shape == (10, 4) and ds.epochs_completed == 1
+
+
+def test_batch_packer_H5_toy_stream():
+    """Hand-derived table: reads of 3/9/2 windows, B=4, L=2, ratio 1."""
+    L, B = 2, 4
+    reads = [("a", 3), ("b", 9), ("c", 2)]
+    packer = ce.BatchPacker(B, L, 1.0)
+    batches = []
+    for name, n in reads:
+        ev = np.arange(n * L, dtype=np.float32).reshape(n, L) + (ord(name) - 96) * 100
+        ln = np.full(n, L, dtype=np.int32)
+        ln[-1] = 1
+        batches += list(packer.add_read(name, ev, ln))
+    last = packer.flush()
+    assert last is not None
+    batches.append(last)
+    assert [b.n_valid for b in batches] == [4, 4, 4, 2]
+    assert batches[0].fname.tolist() == ["a", "a", "a", "b"] and batches[0].index.tolist() == [0, 0, 0, 0]
+    assert batches[1].fname.tolist() == ["b"] * 4 and batches[1].index.tolist() == [1, 1, 1, 1]
+    assert batches[2].fname.tolist() == ["b"] * 4 and batches[2].index.tolist() == [5, 5, 5, 5]
+    assert batches[3].fname.tolist() == ["c", "c", "", ""] and batches[3].index.tolist() == [0, 0, -1, -1]
+    # wrap padding repeats the real rows (np.pad mode='wrap', chiron_eval.py:352-360)
+    assert np.array_equal(batches[3].x[2], batches[3].x[0]) and np.array_equal(batches[3].x[3], batches[3].x[1])
+    assert batches[3].seq_len.tolist() == [2, 1, 2, 1]
+    assert batches[0].seq_len.tolist() == [2, 2, 1, 2] and batches[0].seq_len.dtype == np.int32
+
+
+def test_seq_len_round_half_even():
+    from chiron_amd import seq_len_for_engine
+    # RNA shipped ratio 5: 2.5 -> 2, 7.5 -> 8 (np.round), chiron_eval.py:337
+    assert seq_len_for_engine([12, 13, 37, 38, 500, 0], 5.0).tolist() == [2, 3, 7, 8, 100, 0]
+
+
+def test_sparse_P1(golden):
+    for c in golden["sparse"]:
+        sp = ce.SparseTensor(np.asarray(c["indices"], dtype=np.int64).reshape(-1, 2), np.asarray(c["values"], dtype=np.int64),
+                             np.asarray(c["dense_shape"], dtype=np.int64))
+        logp = np.asarray(c["logp"], dtype=np.float32).reshape(-1, 1)
+        reads, uniq = ce.sparse2dense(([sp], logp))
+        assert [list(map(int, r)) for r in reads[0]] == c["reads"]
+        assert list(map(int, uniq[0])) == c["uniq"]
+        s, e = c["slice"]
+        sl, lp = ce.slice_ctc_decoding_result(([sp], logp), s, e)
+        assert sl[0].indices.tolist() == c["slice_indices"] and sl[0].values.tolist() == c["slice_values"]
+        assert list(map(int, sl[0].dense_shape)) == c["slice_shape"]
+        assert lp.ravel().tolist() == c["slice_logp"]
+
+
+def test_index2base_kernal_mapping_P2_A1(golden):
+    for c in golden["index2base"]:
+        assert ce.index2base(c["in"]) == c["out"]
+    for c in golden["assembler_kernal"]:
+        assert ce.get_assembler_kernal(c["jump"], c["seg"]) == c["out"]
+    for c in golden["mapping"]:
+        assert list(map(int, assembly.mapping(c["in"]))) == c["out"]
+
+
+def test_qs_Q1(golden):
+    for c in golden["qs"]:
+        cons, cqs = np.asarray(c["consensus"]), np.asarray(c["consensus_qs"])
+        assert ce.qs(cons, cqs) == c["phred"]
+        assert ce.qs(cons, cqs, "number").tolist() == c["number"]
+
+
+def test_kernels_A2(golden, built):
+    for p in golden["kernels"]:
+        assert assembly.glue_kernal(p["cur"], p["prev"]) == p["glue"]
+        assert assembly.stick_kernal(p["cur"], p["prev"]) == p["stick"]
+        for key, jr in (("simple", 0.075), ("simple_975", 0.975)):
+            if key in p:
+                d, lp = assembly.simple_assembly_kernal(p["cur"], p["prev"], 0.2, jr)
+                assert [d, lp] == p[key]
+        # the native (C++) glue agrees with the Python form on every pair
+        if p["cur"] and p["prev"]:
+            cons = assembly.simple_assembly([p["prev"], p["cur"]], 0.975, kernal="glue")
+            assert cons.shape[1] == p["glue"] + len(p["cur"])
+
+
+def test_assembly_A3(golden, built):
+    for c in golden["assembly"]:
+        qsl = np.asarray(c["qs_list"]).reshape(-1, 1)
+        cons = assembly.simple_assembly(c["chunks"], c["jump_ratio"], kernal=c["kernal"])
+        cq, cqs = assembly.simple_assembly_qs(c["chunks"], qsl, c["jump_ratio"], kernal=c["kernal"])
+        assert np.array_equal(cons, np.asarray(c["consensus"], dtype=np.float64))
+        assert np.array_equal(cq, cons)
+        np.testing.assert_allclose(cqs, np.asarray(c["consensus_qs"]), rtol=1e-12, atol=0)
+        assert ce.index2base(np.argmax(cons, axis=0)) == c["argmax"]
+        assert ce.qs(cq, cqs) == c["qs_string"]
+
+
+def test_assembly_quirks(built):
+    """single segment -> empty consensus (the reference's `continue` skips the length update);
+    no segments -> empty."""
+    assert assembly.simple_assembly(["ACGT"], 0.975, kernal="glue").shape == (4, 0)
+    assert assembly.simple_assembly([], 0.975, kernal="glue").shape == (4, 0)
+    c = assembly.simple_assembly(["ACGTACGTACGTACGTACGTACGT", "A"], 0.975, kernal="stick")
+    assert c.shape == (4, 25)
+
+
+@pytest.mark.parametrize("i", [1, 2, 3, 4, 5])
+def test_example_reads_segments_to_result(golden, built, i):
+    """The reference's checked-in example: segments/readN.fastq -> result/readN.fastq sequence line, exact
+    (glue, jump 390 / segment 400).  Pins rows A1-A3 end to end."""
+    lines = open(os.path.join(EX, "segments", "read%d.fastq" % i)).read().split("\n")
+    segs = [lines[j + 1] for j in range(0, len(lines) - 1, 2) if lines[j].startswith(">")]
+    assert len(segs) == golden["example_consensus"]["read%d" % i]["n_segments"]
+    cons = assembly.simple_assembly(segs, 390 / 400, kernal=ce.get_assembler_kernal(390, 400))
+    seq = ce.index2base(np.argmax(cons, axis=0))
+    want = open(os.path.join(EX, "result", "read%d.fastq" % i)).read().split("\n")[1]
+    assert seq == want and len(seq) == golden["example_consensus"]["read%d" % i]["len"]
+
+
+def test_write_output_O1(tmp_path):
+    class F(object):
+        output = str(tmp_path)
+        mode = "dna"
+        batch_size, segment_len, jump, start = 400, 400, 390, 0
+        input, model = "in/", "model/"
+    import time
+    t0 = time.time()
+    ce.write_output(["ACG", "TT"], "ACGTT", [t0, 0.1, 0.2, 0.3], "read1", F, suffix="fastq", q_score="!!!!!")
+    assert open(os.path.join(str(tmp_path), "result", "read1.fastq")).read() == "@read1\nACGTT\n+\n!!!!!\n"
+    assert open(os.path.join(str(tmp_path), "segments", "read1.fastq")).read() == ">read10\nACG\n>read11\nTT\n"
+    meta = open(os.path.join(str(tmp_path), "meta", "read1.meta")).read().split("\n")
+    assert meta[0] == "# Reading Basecalling assembly output total rate(bp/s)"
+    assert meta[2] == "# read_len batch_size segment_len jump start_pos" and meta[3] == "5 400 400 390 0"
+    assert meta[5] == "in/ model/"
+    F.mode = "rna"
+    ce.write_output(["ACG"], "ACGTT", [t0, 0.1, 0.2, 0.3], "r2", F, suffix="fasta", concise=True)
+    assert open(os.path.join(str(tmp_path), "result", "r2.fasta")).read() == ">r2\nACGUU"
+
+
+def test_presets_E0():
+    p = entry.build_parser()
+    a = entry.resolve_preset(p.parse_args(["call", "-i", "x", "-o", "y"]))
+    assert (a.batch_size, a.segment_len, a.jump, a.beam, a.start) == (400, 500, 490, 30, 0)
+    a = entry.resolve_preset(p.parse_args(["call", "-i", "x", "-o", "y", "-p", "dna-pre", "-b", "1100", "--beam", "0"]))
+    assert (a.batch_size, a.segment_len, a.jump, a.beam) == (1100, 400, 390, 0)
+    a = entry.resolve_preset(p.parse_args(["call", "-i", "x", "-o", "y", "-p", "rna-pre", "--mode", "rna"]))
+    assert (a.batch_size, a.segment_len, a.jump) == (300, 2000, 1900)
+    with pytest.raises(ValueError):
+        entry.resolve_preset(p.parse_args(["call", "-i", "x", "-o", "y", "-p", "dna-pre", "--mode", "rna"]))
+    with pytest.raises(ValueError):
+        entry.resolve_preset(p.parse_args(["call", "-i", "x", "-o", "y", "-p", "rna-pre"]))
+    with pytest.raises(ValueError):
+        entry.resolve_preset(p.parse_args(["call", "-i", "x", "-o", "y", "-p", "bogus"]))
+
+
+def test_read_collector_orders_pieces_by_window_index():
+    """A read spanning 3 batches is re-assembled in within-file order even when batches are drained
+    out of order (intended semantic)."""
+    from chiron_amd.engine import DecodeResult, SparseTensor
+    col = ce.ReadCollector()
+    col.expect("b", 9, (0.0, 0.0))
+
+    def mk(batch_rows, first_idx, base):
+        fn = np.asarray(["b"] * batch_rows, dtype=object)
+        idx = np.full(batch_rows, first_idx)
+        ind = np.asarray([[r, 0] for r in range(batch_rows)], dtype=np.int64)
+        val = np.asarray([(base + r) % 4 for r in range(batch_rows)], dtype=np.int64)
+        res = DecodeResult(SparseTensor(ind, val, np.asarray([batch_rows, 1])), np.zeros((batch_rows, 1), np.float32),
+                           np.arange(batch_rows, dtype=np.float32).reshape(-1, 1) + base, None)
+        return ce.Batch(None, None, fn, idx, batch_rows), res
+    b2, r2 = mk(4, 5, 5)
+    b0, r0 = mk(1, 0, 0)
+    b1, r1 = mk(4, 1, 1)
+    assert col.add_batch(b2, r2, True) == []
+    assert col.add_batch(b0, r0, True) == []
+    done = col.add_batch(b1, r1, True)
+    assert len(done) == 1
+    name, reads, qs_list, meta = done[0]
+    assert [int(r[0]) for r in reads] == [i % 4 for i in range(9)]
+    assert qs_list.ravel().tolist() == list(map(float, range(9)))
