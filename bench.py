@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--slots", type=int, default=2, help="batches in flight (engine slots / HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -74,7 +75,7 @@ def main():
     from chiron_amd import assembly
     spec = ca.dna_default_spec()
     weights = ca.synthetic_weights(spec, seed=1234)
-    eng = ca.Engine(spec, weights, max_batch=BATCH, segment_len=SEG_LEN, device_id=local_rank, n_slots=2)
+    eng = ca.Engine(spec, weights, max_batch=BATCH, segment_len=SEG_LEN, device_id=local_rank, n_slots=args.slots)
 
     n_distinct = 4
     xb, lb, tags, win_per_read = make_batches(n_distinct, rank)
@@ -98,19 +99,19 @@ def main():
             consensus_bases[0] += int(cons[0].shape[1])
 
     def step(i, pending):
-        slot = i % 2
+        slot = i % args.slots
         if pending[slot]:
             consume(eng.collect(slot))
         eng.submit(slot, x_dev[i % n_distinct], s_dev[i % n_distinct], beam_width=0, want_prob=True)
         pending[slot] = True
 
     def drain(pending):
-        for slot in (0, 1):
+        for slot in range(args.slots):
             if pending[slot]:
                 consume(eng.collect(slot))
                 pending[slot] = False
 
-    pending = [False, False]
+    pending = [False] * args.slots
     for i in range(args.warmup):
         step(i, pending)
     drain(pending)
@@ -177,7 +178,7 @@ def main():
             "config": {"workload": "DNA_default seg_len=400 jump=390 batch=1100 greedy, synthetic 4 kHz signal "
                                    "(BASELINE.json configs[1])", "segment_len": SEG_LEN, "jump": JUMP,
                        "batch": BATCH, "decode": "greedy", "weights": "seeded synthetic (exact checkpoint shapes)",
-                       "parallelism": "reads sharded per GPU, no collective", "slots_in_flight": 2},
+                       "parallelism": "reads sharded per GPU, no collective", "slots_in_flight": args.slots},
             "roofline": roofline, "cpu_baseline": cpu,
             "extra": {"windows_per_s": round(windows / dt, 1),
                       "decoded_bases_per_s": round(decoded_bases[0] / dt, 1),
@@ -201,7 +202,7 @@ def cpu_baseline(spec, weights, xb, lb, ratio, n_windows):
     threads = c_oracle.max_threads()
     cores = os.cpu_count() or threads
     threads = min(threads, cores)
-    n = n_windows if n_windows > 0 else max(threads * 2, 16)
+    n = n_windows if n_windows > 0 else max(threads * 24, 64)
     n = min(n, xb.shape[0] * xb.shape[1])
     x = xb.reshape(-1, SEG_LEN)[:n]
     sl = ca.seq_len_for_engine(lb.reshape(-1)[:n], ratio)
