@@ -14,6 +14,10 @@
 //   t = seq_len-1-s per row (tf.reverse_sequence folded into index arithmetic, no copy).
 #include "kernels.h"
 
+// Every multiply-add below is written out (fmaf or separate ops) so that a row's result does not depend on
+// which register slot / row position it occupies: batches can be re-packed without changing a bit.
+#pragma clang fp contract(off)
+
 namespace chiron {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -25,7 +29,7 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 }
 __device__ __forceinline__ float fast_tanh(float x) {
   // 1 - 2/(e^{2x}+1); saturates correctly at +-inf, |abs err| ~1e-7
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f), 1.0f);
 }
 
 template <int KS>
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void lstm_kernel(const LstmParams p) {
         const float gj = acc[u * 4 + 1][r] + z[u * 4 + 1][r];
         const float gf = acc[u * 4 + 2][r] + z[u * 4 + 2][r];
         const float go = acc[u * 4 + 3][r] + z[u * 4 + 3][r];
-        const float cn = fast_sigmoid(gf) * c[u][r] + fast_sigmoid(gi) * fast_tanh(gj);
+        const float cn = fmaf(fast_sigmoid(gf), c[u][r], fast_sigmoid(gi) * fast_tanh(gj));
         const float hnew = fast_sigmoid(go) * fast_tanh(cn);
         if (act[r]) {
           c[u][r] = cn;
