@@ -723,33 +723,8 @@ static void run_rnn(chiron_engine* e, Slot* s, int B) {
   }
 }
 
-extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, const float* x, const int32_t* seq_len,
-                                              int32_t batch, int32_t beam_width, uint32_t flags) {
-  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
-  if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range (%zu slots)", slot, e->slots.size());
-  if (!x || !seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
-  if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
-  if (beam_width < 0) return fail(CHIRON_ERR_INVALID, "beam_width %d", beam_width);
-  if (beam_width > e->opts.max_beam) return fail(CHIRON_ERR_OVERFLOW, "beam_width %d exceeds max_beam %d given at create", beam_width, e->opts.max_beam);
-  Slot* s = &e->slots[slot];
-  HIP_TRY(hipSetDevice(e->opts.device_id));
-  if (s->busy) HIP_TRY(hipStreamSynchronize(s->stream));
-  const int B = batch, T = e->T, K = e->K;
-  const float* sig;
-  HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
-  if (flags & CHIRON_X_ON_DEVICE) {
-    sig = x;
-    HIP_TRY(hipMemcpyAsync(s->seq, seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
-  } else {
-    memcpy(s->h_sig, x, (size_t)B * e->L * 4);
-    memcpy(s->h_seq, seq_len, (size_t)B * 4);
-    HIP_TRY(hipMemcpyAsync(s->sig, s->h_sig, (size_t)B * e->L * 4, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->seq, s->h_seq, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
-    sig = s->sig;
-  }
-  run_cnn(e, s, B, sig);
-  run_rnn(e, s, B);
-
+static chiron_status enqueue_decode(chiron_engine* e, Slot* s, int B, int beam_width, uint32_t flags) {
+  const int T = e->T, K = e->K;
   if (beam_width == 0) {
     GreedyParams g;
     g.logits = s->logits;
@@ -795,9 +770,75 @@ extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, co
   if (flags & CHIRON_WANT_LOGITS)
     HIP_TRY(hipMemcpyAsync(s->h_logits, s->logits, (size_t)B * T * K * 4, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipGetLastError());
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, const float* x, const int32_t* seq_len,
+                                              int32_t batch, int32_t beam_width, uint32_t flags) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range (%zu slots)", slot, e->slots.size());
+  if (!x || !seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
+  if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
+  if (beam_width < 0) return fail(CHIRON_ERR_INVALID, "beam_width %d", beam_width);
+  if (beam_width > e->opts.max_beam) return fail(CHIRON_ERR_OVERFLOW, "beam_width %d exceeds max_beam %d given at create", beam_width, e->opts.max_beam);
+  Slot* s = &e->slots[slot];
+  HIP_TRY(hipSetDevice(e->opts.device_id));
+  if (s->busy) HIP_TRY(hipStreamSynchronize(s->stream));
+  const int B = batch, T = e->T, K = e->K;
+  const float* sig;
+  HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
+  if (flags & CHIRON_X_ON_DEVICE) {
+    sig = x;
+    HIP_TRY(hipMemcpyAsync(s->seq, seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
+  } else {
+    memcpy(s->h_sig, x, (size_t)B * e->L * 4);
+    memcpy(s->h_seq, seq_len, (size_t)B * 4);
+    HIP_TRY(hipMemcpyAsync(s->sig, s->h_sig, (size_t)B * e->L * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->seq, s->h_seq, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
+    sig = s->sig;
+  }
+  run_cnn(e, s, B, sig);
+  run_rnn(e, s, B);
+
+  {
+    chiron_status st = enqueue_decode(e, s, B, beam_width, flags);
+    if (st) return st;
+  }
+  HIP_TRY(hipGetLastError());
   s->busy = true;
   s->batch = B;
   s->flags = flags;
+  return CHIRON_OK;
+}
+
+// Decode-only entry: run the decode sub-graph (chiron_eval.py:465-492) on caller-supplied logits.
+extern "C" chiron_status chiron_engine_decode(chiron_engine* e, int32_t slot, const float* logits, const int32_t* seq_len,
+                                              int32_t batch, int32_t beam_width, uint32_t flags) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range (%zu slots)", slot, e->slots.size());
+  if (!logits || !seq_len) return fail(CHIRON_ERR_INVALID, "null logits/seq_len");
+  if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
+  if (beam_width < 0) return fail(CHIRON_ERR_INVALID, "beam_width %d", beam_width);
+  if (beam_width > e->opts.max_beam) return fail(CHIRON_ERR_OVERFLOW, "beam_width %d exceeds max_beam %d given at create", beam_width, e->opts.max_beam);
+  Slot* s = &e->slots[slot];
+  HIP_TRY(hipSetDevice(e->opts.device_id));
+  if (s->busy) HIP_TRY(hipStreamSynchronize(s->stream));
+  const size_t nlog = (size_t)batch * e->T * e->K * 4;
+  HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
+  const hipMemcpyKind kind = (flags & CHIRON_X_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (!(flags & CHIRON_X_ON_DEVICE)) {
+    memcpy(s->h_logits, logits, nlog);
+    memcpy(s->h_seq, seq_len, (size_t)batch * 4);
+    logits = s->h_logits;
+    seq_len = s->h_seq;
+  }
+  HIP_TRY(hipMemcpyAsync(s->logits, logits, nlog, kind, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->seq, seq_len, (size_t)batch * 4, kind, s->stream));
+  chiron_status st = enqueue_decode(e, s, batch, beam_width, flags & ~CHIRON_WANT_LOGITS);
+  if (st) return st;
+  s->busy = true;
+  s->batch = batch;
+  s->flags = flags & ~CHIRON_WANT_LOGITS;
   return CHIRON_OK;
 }
 

@@ -121,6 +121,19 @@ class Engine(object):
         self.submit(slot, x, seq_len, beam_width, want_prob, want_logits)
         return self.collect(slot)
 
+    def decode(self, logits, seq_len, beam_width=0, want_prob=True, slot=0):
+        """Decode-only (chiron_eval.decoding_queue): logits float32 [batch, T, K] on the host."""
+        logits = np.ascontiguousarray(logits, dtype=np.float32)
+        seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
+        if logits.ndim != 3 or logits.shape[1] != self.T or logits.shape[2] != self.spec.classes:
+            raise ValueError("logits must be [batch, %d, %d]" % (self.T, self.spec.classes))
+        flags = _lib.WANT_PROB if want_prob else 0
+        self._keep[slot] = (logits, seq_len)
+        _lib.check(self._lib.chiron_engine_decode(self._h, slot, logits.ctypes.data_as(C.c_void_p),
+                                                  seq_len.ctypes.data_as(C.c_void_p), logits.shape[0],
+                                                  int(beam_width), flags))
+        return self.collect(slot)
+
     def sync(self):
         _lib.check(self._lib.chiron_engine_sync(self._h))
 

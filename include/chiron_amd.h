@@ -126,6 +126,12 @@ chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out_T, double*
 chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, const float* x, const int32_t* seq_len,
                                    int32_t batch, int32_t beam_width, uint32_t flags);
 
+/* Decode-only: the decode sub-graph of the reference (decoding_queue, chiron_eval.py:465-492: path_prob +
+ * ctc_greedy_decoder / ctc_beam_search_decoder) on caller-supplied logits float32 [batch, T, K] (T from
+ * chiron_engine_dims).  Same flags, slot and collect protocol as chiron_engine_submit.                  */
+chiron_status chiron_engine_decode(chiron_engine* e, int32_t slot, const float* logits, const int32_t* seq_len,
+                                   int32_t batch, int32_t beam_width, uint32_t flags);
+
 /* The reference's decoded tuple (chiron_eval.py:403-409): SparseTensor
  * (indices, values, dense_shape) + log_prob + prob_logits (+ logits).          */
 typedef struct {

@@ -23,6 +23,9 @@ def load():
         _lib.chiron_oracle_greedy.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.chiron_oracle_max_threads.restype = C.c_int
+        _lib.chiron_oracle_beam.restype = C.c_int
+        _lib.chiron_oracle_beam.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -68,3 +71,20 @@ def greedy(logits, seq_len):
                              neg.ctypes.data, pp.ctypes.data)
     rows = [labels[b, :count[b]].astype(int).tolist() for b in range(B)]
     return rows, neg.reshape(-1, 1), pp.reshape(-1, 1)
+
+
+def beam(logits, seq_len, beam_width):
+    """float32 restatement of TF's sequential CTC beam search (top path) -> (rows, log_prob [B,1])."""
+    lib = load()
+    lg = np.ascontiguousarray(logits, dtype=np.float32)
+    sl = np.ascontiguousarray(seq_len, dtype=np.int32)
+    B, T, K = lg.shape
+    labels = np.zeros((B, T), dtype=np.uint8)
+    count = np.zeros(B, dtype=np.int32)
+    lp = np.zeros(B, dtype=np.float32)
+    rc = lib.chiron_oracle_beam(lg.ctypes.data, sl.ctypes.data, B, T, K, int(beam_width), labels.ctypes.data,
+                                count.ctypes.data, lp.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("chiron_oracle_beam failed: %d" % rc)
+    rows = [labels[b, :count[b]].astype(int).tolist() for b in range(B)]
+    return rows, lp.reshape(-1, 1)

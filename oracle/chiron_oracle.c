@@ -267,3 +267,157 @@ int chiron_oracle_max_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * CTC beam search, float32: sequential restatement of TF 1.15 CTCBeamSearchDecoder<>::Step / TopPaths
+ * (core/util/ctc/ctc_beam_search.h, ctc_beam_entry.h, ctc_loss_util.h) with
+ * top_paths=1, merge_repeated=False as the reference calls it (chiron_eval.py:489-492).
+ * Includes TF's sequential is_candidate pruning against the moving bottom of the top-N container.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int parent, label, child[4];
+  float o_total, o_blank, o_label, n_total, n_blank, n_label;
+  int in_leaves;
+} bnode;
+
+static float lse2(float a, float b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  return a > b ? a + log1pf(expf(b - a)) : b + log1pf(expf(a - b));
+}
+
+static int bottom_of(const bnode* nd, const int* leaves, int nl) {
+  int bi = 0;
+  for (int i = 1; i < nl; ++i)
+    if (nd[leaves[i]].n_total < nd[leaves[bi]].n_total) bi = i;
+  return bi;
+}
+
+/* logits [B][T][K] (K == 5); labels [B][T]; count [B]; log_prob [B] */
+int chiron_oracle_beam(const float* logits, const int* seq_len, int B, int T, int K, int beam, unsigned char* labels,
+                       int* count, float* log_prob) {
+  if (K != 5 || beam < 1) return -1;
+  const int blank = K - 1;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b) {
+    int len = seq_len[b];
+    if (len < 0) len = 0;
+    if (len > T) len = T;
+    size_t cap = 1 + (size_t)4 * beam * (len + 1) + 16;
+    bnode* nd = (bnode*)malloc(sizeof(bnode) * cap);
+    int* leaves = (int*)malloc(sizeof(int) * (beam + 1));
+    int* branches = (int*)malloc(sizeof(int) * (beam + 1));
+    int nn = 1, nl = 1;
+    nd[0].parent = -1;
+    nd[0].label = -1;
+    for (int c = 0; c < 4; ++c) nd[0].child[c] = -1;
+    nd[0].n_total = 0.f;
+    nd[0].n_blank = 0.f;
+    nd[0].n_label = -INFINITY;
+    nd[0].in_leaves = 1;
+    leaves[0] = 0;
+    for (int t = 0; t < len; ++t) {
+      const float* lg = logits + ((size_t)b * T + t) * K;
+      float mx = lg[0], s = 0.f, logp[5];
+      for (int k = 1; k < K; ++k) mx = lg[k] > mx ? lg[k] : mx;
+      for (int k = 0; k < K; ++k) s += expf(lg[k] - mx);
+      const float lse = logf(s);
+      for (int k = 0; k < K; ++k) logp[k] = (lg[k] - mx) - lse;
+      /* branches = leaves sorted by descending newp.total (insertion sort, stable) */
+      int nbr = nl;
+      for (int i = 0; i < nl; ++i) branches[i] = leaves[i];
+      for (int i = 1; i < nbr; ++i) {
+        int v = branches[i], j = i - 1;
+        while (j >= 0 && nd[branches[j]].n_total < nd[v].n_total) {
+          branches[j + 1] = branches[j];
+          --j;
+        }
+        branches[j + 1] = v;
+      }
+      nl = 0;
+      for (int i = 0; i < nbr; ++i) {
+        bnode* e = &nd[branches[i]];
+        e->o_total = e->n_total;
+        e->o_blank = e->n_blank;
+        e->o_label = e->n_label;
+        e->in_leaves = 0;
+      }
+      for (int i = 0; i < nbr; ++i) {
+        bnode* e = &nd[branches[i]];
+        if (e->parent >= 0) {
+          const bnode* pa = &nd[e->parent];
+          if (pa->n_total != -INFINITY) { /* parent Active() */
+            const float prev = (e->label == pa->label) ? pa->o_blank : pa->o_total;
+            e->n_label = lse2(e->n_label, prev);
+          }
+          e->n_label += logp[e->label];
+        }
+        e->n_blank = e->o_total + logp[blank];
+        e->n_total = lse2(e->n_blank, e->n_label);
+        e->in_leaves = 1;
+        leaves[nl++] = branches[i];
+      }
+      for (int i = 0; i < nbr; ++i) {
+        const int bi = branches[i];
+        /* is_candidate(b->oldp) */
+        {
+          const float tot = nd[bi].o_total;
+          int ok = tot > -INFINITY;
+          if (ok && nl >= beam) ok = tot > nd[leaves[bottom_of(nd, leaves, nl)]].n_total;
+          if (!ok) continue;
+        }
+        for (int c = 0; c < blank; ++c) {
+          int ci = nd[bi].child[c];
+          if (ci < 0) {
+            ci = nn++;
+            nd[ci].parent = bi;
+            nd[ci].label = c;
+            for (int q = 0; q < 4; ++q) nd[ci].child[q] = -1;
+            nd[ci].n_total = nd[ci].n_blank = nd[ci].n_label = -INFINITY;
+            nd[ci].o_total = nd[ci].o_blank = nd[ci].o_label = -INFINITY;
+            nd[ci].in_leaves = 0;
+            nd[bi].child[c] = ci;
+          }
+          bnode* ch = &nd[ci];
+          if (ch->n_total != -INFINITY) continue; /* Active(): handled with the branches */
+          ch->n_blank = -INFINITY;
+          const float prev = (c == nd[bi].label) ? nd[bi].o_blank : nd[bi].o_total;
+          ch->n_label = logp[c] + prev;
+          ch->n_total = ch->n_label;
+          int cand = ch->n_total > -INFINITY;
+          int bot = -1;
+          if (cand && nl >= beam) {
+            bot = bottom_of(nd, leaves, nl);
+            cand = ch->n_total > nd[leaves[bot]].n_total;
+          }
+          if (cand) {
+            if (nl >= beam) {
+              bnode* bt = &nd[leaves[bot]];
+              bt->n_total = bt->n_blank = bt->n_label = -INFINITY;
+              bt->in_leaves = 0;
+              leaves[bot] = leaves[--nl];
+            }
+            ch->in_leaves = 1;
+            leaves[nl++] = ci;
+          } else {
+            ch->o_total = ch->o_blank = ch->o_label = -INFINITY;
+            ch->n_total = ch->n_blank = ch->n_label = -INFINITY;
+          }
+        }
+      }
+    }
+    int best = leaves[0];
+    for (int i = 1; i < nl; ++i)
+      if (nd[leaves[i]].n_total > nd[best].n_total) best = leaves[i];
+    int depth = 0;
+    for (int e = best; nd[e].parent >= 0; e = nd[e].parent) ++depth;
+    count[b] = depth;
+    log_prob[b] = nd[best].n_total;
+    int pos = depth;
+    for (int e = best; nd[e].parent >= 0; e = nd[e].parent) labels[(size_t)b * T + --pos] = (unsigned char)nd[e].label;
+    free(nd);
+    free(leaves);
+    free(branches);
+  }
+  return 0;
+}

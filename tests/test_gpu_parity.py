@@ -203,3 +203,92 @@ def test_pipeline_end_to_end_on_example_signal(dna, tmp_path):
     assert seg[0] == ">read10" and seg[1] == bp[0] and len(seg) == 2 * len(bp) + 1
     assert os.path.exists(os.path.join(F.output, "meta", "read1.meta"))
     assert open(os.path.join(F.output, "result", "tiny.fastq")).read().startswith("@tiny\n")
+
+
+def _check_beam(res, logits, sl, beam, B):
+    """Device beam search vs the sequential float32 restatement of TF's decoder.
+
+    TF's algorithm is discontinuous: at a numerical near-tie (which leaf is the top-N bottom, which of two
+    totals is larger) one flipped comparison can kill a branch (the oldp.Reset() quirk) and change the decoded
+    row and its score by O(1) nats -- the float32 C oracle and the float64 Python oracle disagree with each
+    other on ~1 row in 50 of flat random posteriors for the same reason.  So: rows must be identical except
+    for a small fraction of near-tie rows; matching rows must also match in score."""
+    from oracle import c_oracle, ctc_oracle
+    rows, lp = c_oracle.beam(logits, sl, beam)
+    got = [[] for _ in range(B)]
+    for (r, _), v in zip(res.decoded.indices, res.decoded.values):
+        got[r].append(int(v))
+    bad = [b for b in range(B) if got[b] != rows[b]]
+    assert len(bad) <= max(1, B // 20), "too many beam rows differ: %d of %d" % (len(bad), B)
+    good = np.asarray([b for b in range(B) if b not in bad], dtype=int)
+    # scores: equal up to float noise, except where a near-tie re-routed probability mass inside the beam
+    off = np.abs(res.log_prob[good] - lp[good]).ravel() > 2e-3
+    assert off.sum() <= max(1, B // 10), "beam log-probabilities differ on %d of %d rows" % (off.sum(), B)
+    if not bad:
+        idx, val, shape = ctc_oracle.rows_to_sparse(rows, B)
+        assert np.array_equal(res.decoded.indices, idx) and np.array_equal(res.decoded.values, val)
+        assert np.array_equal(res.decoded.dense_shape, shape)
+    # structural invariants of the SparseTensor hold for every row
+    assert res.decoded.dense_shape[0] == B
+    assert np.all(np.diff(res.decoded.indices[:, 0]) >= 0)
+    np.testing.assert_allclose(res.prob_logits, ctc_oracle.path_prob(logits), rtol=1e-5, atol=1e-5)
+    return len(bad)
+
+
+def test_beam_search_rna_config3(rna):
+    """BASELINE configs[2] shape: RNA topology, segment 500 / jump 490, CTC beam_width = 50."""
+    spec, w = rna
+    L = 500
+    x, ln = _windows(490 * 47 + 200, L, 490, seed=31)
+    B = x.shape[0]
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, max_beam=50) as eng:
+        sl = ca.seq_len_for_engine(ln, eng.ratio)
+        res = eng.infer(x, sl, beam_width=50, want_prob=True, want_logits=True)
+        _check_beam(res, res.logits, sl, 50, B)
+        g = eng.infer(x, sl, beam_width=0, want_logits=True)          # greedy still available on the same engine
+        assert np.array_equal(g.logits, res.logits)
+
+
+@pytest.mark.parametrize("beam", [1, 5, 30, 100, 256])
+def test_beam_search_dna_widths(dna, beam):
+    spec, w = dna
+    L = 400
+    x, ln = _windows(390 * 23 + 50, L, 390, seed=32)
+    B = x.shape[0]
+    ln = ln.copy()
+    ln[3] = 0
+    ln[4] = 1
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, max_beam=256) as eng:
+        sl = ca.seq_len_for_engine(ln, eng.ratio)
+        res = eng.infer(x, sl, beam_width=beam, want_prob=True, want_logits=True)
+    _check_beam(res, res.logits, sl, beam, B)
+    assert res.decoded.dense_shape[0] == B
+
+
+def test_decode_only_entry_brute_force_and_random(dna):
+    """chiron_engine_decode: device decoders on arbitrary logits.  Short sequences are checked against
+    exhaustive CTC enumeration (wide beam == exact), longer random ones against the sequential oracle."""
+    from oracle import ctc_oracle, c_oracle
+    spec, w = dna
+    rng = np.random.RandomState(7)
+    B = 32
+    with ca.Engine(spec, w, max_batch=B, segment_len=400, max_beam=256) as eng:
+        lg = (rng.randn(B, 400, 5) * 2.0).astype(np.float32)
+        sl = rng.randint(0, 7, size=B).astype(np.int32)
+        sl[:3] = [0, 1, 6]
+        res = eng.decode(lg, sl, beam_width=256)
+        got = [[] for _ in range(B)]
+        for (r, _), v in zip(res.decoded.indices, res.decoded.values):
+            got[r].append(int(v))
+        for b in range(B):
+            best, best_lp, _ = ctc_oracle.brute_force_best(lg[b], sl[b])
+            assert got[b] == best
+            assert abs(float(res.log_prob[b, 0]) - best_lp) < 1e-4
+        # greedy through the same entry
+        sl2 = rng.randint(0, 401, size=B).astype(np.int32)
+        g = eng.decode(lg, sl2, beam_width=0)
+        _check_decode(g, lg, sl2, B)
+        # random long sequences, several widths
+        for beam in (2, 50, 200):
+            r = eng.decode(lg, sl2, beam_width=beam)
+            _check_beam(r, lg, sl2, beam, B)

@@ -76,3 +76,25 @@ def test_beam_no_merge_repeated():
     lg[0, 0, 0] = lg[0, 1, 4] = lg[0, 2, 0] = 9.0
     rows, _ = co.beam_search_decode(lg, [3], 10)
     assert rows[0] == [0, 0]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_c_beam_oracle_matches_python_and_exhaustive(built, seed):
+    from oracle import c_oracle
+    rng = np.random.RandomState(100 + seed)
+    T = int(rng.randint(2, 7))
+    lg = (rng.randn(3, T, 5) * 2.0).astype(np.float32)
+    sl = np.asarray([T, T - 1, 0])
+    rows, lp = c_oracle.beam(lg, sl, 512)
+    for b in range(3):
+        best, best_lp, _ = co.brute_force_best(lg[b], sl[b])
+        assert rows[b] == best
+        assert abs(lp[b, 0] - best_lp) < 1e-4
+    # narrow beams: identical to the float64 Python restatement (same sequential pruning rules)
+    lg = (rng.randn(8, 40, 5) * 2.5).astype(np.float32)
+    sl = rng.randint(1, 41, size=8)
+    for w in (1, 3, 30):
+        r1, l1 = c_oracle.beam(lg, sl, w)
+        r2, l2 = co.beam_search_decode(lg, sl, w)
+        assert r1 == r2
+        np.testing.assert_allclose(l1, l2, rtol=0, atol=1e-4)
