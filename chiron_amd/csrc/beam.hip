@@ -165,7 +165,9 @@ __global__ __launch_bounds__(64) void beam_kernel(const BeamParams p, int node_c
       if (!(ot > NEG_INF)) continue;
       if (nL >= W) {  // is_candidate(b->oldp)
         if (!bot_valid) find_bottom();
-        if (!(ot > bot_val)) continue;
+        // branches come in descending old total and the bottom never decreases: once one fails, all
+        // later ones fail too (TF would `continue` through every one of them to the same effect)
+        if (!(ot > bot_val)) break;
       }
       const float oblk = uni(E_blk[i]);
       const int lc = uni(E_lc[i]);

@@ -242,6 +242,17 @@ def main():
                             os.path.join(dst, sub, "read%d.fastq" % i))
     shutil.copyfile(sig_path, os.path.join(dst, "raw", "read1.signal"))
     shutil.copyfile(os.path.join(EX, "read1.fast5"), os.path.join(dst, "read1.fast5"))
+    # checkpoint metadata of the shipped models (index = variable names/shapes/offsets; the *.data
+    # blobs are stripped from the reference tree): model folders usable with --synthetic-weights
+    pkg_models = os.path.join(os.path.dirname(os.path.dirname(HERE)), "chiron_amd", "model")
+    for m in ("DNA_default", "RNA_default"):
+        src = os.path.join(REF, "chiron", "model", m)
+        os.makedirs(os.path.join(pkg_models, m), exist_ok=True)
+        for fn in os.listdir(src):
+            if fn.endswith(".meta"):
+                continue
+            shutil.copyfile(os.path.join(src, fn), os.path.join(pkg_models, m, fn))
+            os.chmod(os.path.join(pkg_models, m, fn), 0o644)
     for p, _, fs in os.walk(dst):
         for fn in fs:
             os.chmod(os.path.join(p, fn), 0o644)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Secondary BASELINE.json configs (parity-test cases, not the headline bench line): timing only.
+  configs[2]: RNA_default --mode rna, seg_len=500 jump=490 batch=400, CTC beam_width=50
+  DNA beam:   DNA_default batch=1100 with the reference's preset beam widths (30 / 50)
+"""
+import json
+import sys
+import time
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import chiron_amd as ca
+from chiron_amd import signal_io
+
+
+def run(name, spec, L, jump, B, beam, steps=6):
+    w = ca.synthetic_weights(spec, seed=1234)
+    sig = ca.synthetic_signal(1, jump * (B - 1) + L, seed=5)[0]
+    x, ln = signal_io.window_signal(sig, 0, jump, L)
+    x, ln = x[:B], ln[:B]
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=2, max_beam=beam) as eng:
+        sl = ca.seq_len_for_engine(ln, eng.ratio)
+        for _ in range(2):
+            eng.infer(x, sl, beam_width=beam)
+        eng.sync()
+        t0 = time.perf_counter()
+        pend = [False, False]
+        nb = 0
+        for i in range(steps):
+            s = i % 2
+            if pend[s]:
+                nb += eng.collect(s).decoded.values.shape[0]
+            eng.submit(s, x, sl, beam_width=beam, want_prob=True)
+            pend[s] = True
+        for s in (0, 1):
+            if pend[s]:
+                nb += eng.collect(s).decoded.values.shape[0]
+        dt = time.perf_counter() - t0
+        eng.profile(True)
+        eng.infer(x, sl, beam_width=beam)
+        st = eng.profile_read()
+        eng.profile(False)
+    bases_per_window = jump / (4000.0 / 450.0) if "DNA" in name else jump / (3012.0 / 70.0)
+    print(json.dumps({"config": name, "batch": B, "segment_len": L, "jump": jump, "beam": beam, "T": spec.output_len(L),
+                      "ms_per_batch": round(dt / steps * 1e3, 3), "windows_per_s": round(steps * B / dt, 1),
+                      "decoded_bases_per_s": round(nb / dt, 1),
+                      "kernels_ms": {k: round(v["total_ms"] / v["launches"], 4) for k, v in st.items()}}))
+
+
+if __name__ == "__main__":
+    run("RNA_default seg500 jump490 b400 beam50", ca.rna_default_spec(), 500, 490, 400, 50)
+    run("DNA_default seg400 jump390 b1100 beam30", ca.dna_default_spec(), 400, 390, 1100, 30)
+    run("DNA_default seg400 jump390 b1100 beam50", ca.dna_default_spec(), 400, 390, 1100, 50)
+    run("DNA_default seg400 jump390 b1100 greedy", ca.dna_default_spec(), 400, 390, 1100, 0)
