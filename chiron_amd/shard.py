@@ -1,0 +1,55 @@
+"""Per-read sharding across GPUs: reads are independent units, so each rank basecalls
+its own reads and writes its own result files; the only cross-rank step is a host-side FASTA/FASTQ
+gather (what the reference documents as `utils/merge.sh`, README.md:156).  No RCCL collective touches
+the data path -- torch.distributed is used for the barrier only (backend nccl on GPUs, gloo on CPU)."""
+import os
+
+
+def partition_reads(files, world_size, rank, sizes=None):
+    """Deterministic partition of the (sorted) read list.  Without sizes: read k -> rank k mod G.
+    With sizes (bytes or samples): greedy longest-first balancing, ties by name."""
+    files = sorted(files)
+    if world_size <= 1:
+        return files
+    if sizes is None:
+        return [f for k, f in enumerate(files) if k % world_size == rank]
+    load = [0] * world_size
+    owner = {}
+    for f in sorted(files, key=lambda x: (-sizes[x], x)):
+        r = min(range(world_size), key=lambda i: (load[i], i))
+        owner[f] = r
+        load[r] += sizes[f]
+    return [f for f in files if owner[f] == rank]
+
+
+def gather_results(output_dir, extension="fastq", merged_name="merged"):
+    """Concatenate result/<read>.<ext> (sorted by name) into <output>/<merged_name>.<ext>."""
+    res = os.path.join(output_dir, "result")
+    names = sorted(n for n in os.listdir(res) if n.endswith("." + extension))
+    out_path = os.path.join(output_dir, merged_name + "." + extension)
+    with open(out_path, "w") as out:
+        for n in names:
+            txt = open(os.path.join(res, n)).read()
+            out.write(txt if txt.endswith("\n") else txt + "\n")
+    return out_path, len(names)
+
+
+def run_sharded(FLAGS, basecall_fn, dist=None):
+    """One process per GPU.  basecall_fn(FLAGS, file_list) handles this rank's reads.
+    `dist` is torch.distributed (already initialised) or None for a single process."""
+    from . import eval as chiron_eval
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    files, file_dir = chiron_eval.list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
+    files = [f for f in files if f.endswith(".signal") or f.endswith(".fast5")]
+    sizes = {f: os.path.getsize(os.path.join(file_dir, f)) for f in files}
+    mine = partition_reads(files, world, rank, sizes)
+    out = basecall_fn(FLAGS, mine)
+    if dist is not None:
+        dist.barrier()
+    merged = None
+    if rank == 0:
+        merged = gather_results(FLAGS.output, FLAGS.extension)
+    if dist is not None:
+        dist.barrier()
+    return out, merged

@@ -292,3 +292,31 @@ def test_decode_only_entry_brute_force_and_random(dna):
         for beam in (2, 50, 200):
             r = eng.decode(lg, sl2, beam_width=beam)
             _check_beam(r, lg, sl2, beam, B)
+
+
+def test_chiron_call_cli_on_fast5_folder(tmp_path):
+    """BASELINE configs[0] plumbing: `chiron call` on a folder of fast5 files with model/DNA_default,
+    batch=100, greedy.  The trained weights are stripped from the reference tree, so the CLI runs with
+    --synthetic-weights (exact checkpoint shapes from the shipped .index)."""
+    import shutil
+    from chiron_amd import entry, signal_io
+    inp = tmp_path / "fast5"
+    inp.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "example_dna", "read1.fast5"), str(inp / "read1.fast5"))
+    out = str(tmp_path / "out")
+    model = os.path.join(os.path.dirname(os.path.abspath(ca.__file__)), "model", "DNA_default")
+    entry.main(["call", "-i", str(inp), "-o", out, "-m", model, "-p", "dna-pre", "-b", "100", "--beam", "0",
+                "--synthetic-weights"])
+    # extract step reproduced the reference's raw signal file content
+    assert np.array_equal(signal_io.read_signal(os.path.join(out, "raw", "read1.signal")),
+                          signal_io.read_signal(os.path.join(GOLDEN, "example_dna", "raw", "read1.signal")))
+    fq = open(os.path.join(out, "result", "read1.fastq")).read().split("\n")
+    assert fq[0] == "@read1" and fq[2] == "+" and len(fq[1]) == len(fq[3]) > 0 and set(fq[1]) <= set("ACGT")
+    meta = open(os.path.join(out, "meta", "read1.meta")).read().split("\n")
+    assert meta[3].split()[1:4] == ["100", "400", "390"]
+    assert os.path.exists(os.path.join(out, "meta", "all.meta")) and os.path.isdir(os.path.join(out, "log"))
+    # same read, default preset beam (30): runs through the device beam search
+    out2 = str(tmp_path / "out2")
+    entry.main(["call", "-i", str(inp), "-o", out2, "-m", model, "-p", "dna-pre", "-b", "100", "--synthetic-weights"])
+    fq2 = open(os.path.join(out2, "result", "read1.fastq")).read().split("\n")
+    assert fq2[0] == "@read1" and len(fq2[1]) == len(fq2[3]) > 0
