@@ -87,31 +87,48 @@ def main():
     decoded_bases = [0]
     consensus_bases = [0]
 
-    def consume(res):
-        """host side of a step: ragged split of the SparseTensor + glue consensus over the batch rows"""
+    # rows of a batch that belong to the same read (cross-read packing, chiron_eval.py:321-334)
+    read_of_row = np.asarray([t[0] for t in tags], dtype=np.int64).reshape(n_distinct, BATCH)
+    run_bounds = []
+    for i in range(n_distinct):
+        cuts = np.flatnonzero(np.diff(read_of_row[i])) + 1
+        run_bounds.append(np.concatenate([[0], cuts, [BATCH]]))
+
+    def consume(res, which):
+        """host side of a step: ragged split of the SparseTensor, then the glue overlap-consensus vote
+        (chiron_assemble) for every per-read run of rows in the batch"""
         idx, val = res.decoded.indices, res.decoded.values
         decoded_bases[0] += int(val.shape[0])
-        if val.shape[0]:
-            counts = np.bincount(idx[:, 0], minlength=BATCH)
-            keep = counts[counts > 0]
+        if not val.shape[0]:
+            return
+        counts = np.bincount(idx[:, 0], minlength=BATCH)
+        row_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        v8 = val.astype(np.uint8)
+        bounds = run_bounds[which]
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            c = counts[a:b]
+            keep = c[c > 0]                              # sparse2dense drops rows with an empty decode
+            if keep.shape[0] == 0:
+                continue
+            seg = v8[row_off[a]:row_off[b]]
             off = np.concatenate([[0], np.cumsum(keep)]).astype(np.int64)
-            cons = assembly.assemble_native(val.astype(np.uint8), off, None, "glue")
+            cons = assembly.assemble_native(seg, off, None, "glue")
             consensus_bases[0] += int(cons[0].shape[1])
 
     def step(i, pending):
         slot = i % args.slots
-        if pending[slot]:
-            consume(eng.collect(slot))
+        if pending[slot] is not None:
+            consume(eng.collect(slot), pending[slot])
         eng.submit(slot, x_dev[i % n_distinct], s_dev[i % n_distinct], beam_width=0, want_prob=True)
-        pending[slot] = True
+        pending[slot] = i % n_distinct
 
     def drain(pending):
         for slot in range(args.slots):
-            if pending[slot]:
-                consume(eng.collect(slot))
-                pending[slot] = False
+            if pending[slot] is not None:
+                consume(eng.collect(slot), pending[slot])
+                pending[slot] = None
 
-    pending = [False] * args.slots
+    pending = [None] * args.slots
     for i in range(args.warmup):
         step(i, pending)
     drain(pending)
@@ -162,9 +179,13 @@ def main():
                           "gbps": (s["bytes"] / (s["total_ms"] * 1e-3) / 1e9) if s["total_ms"] > 0 else 0.0}
                       for k, s in stats.items()}
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic("gemm_f32_kernel")
+        gemm_bytes = sum(s["bytes"] for k, s in stats.items() if k.startswith("conv_") or k.startswith("lstm_proj"))
         roofline = {"kernel": "gemm_f32_kernel (conv + LSTM-projection launches)", "bound": "mfma",
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate pass: %s)" % traffic_src,
+                    "algorithmic_bytes_per_launch": gemm_bytes / gemm["launches"],
                     "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
                     "flops_per_launch": gemm["flops"] / gemm["launches"]}
         cpu = None
@@ -192,6 +213,20 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the most recent committed PMC pass under profiles/
+    (tools/pmc_pass.sh + tools/pmc_to_json.py; rocprofv3 cannot run inside the timed process)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not cands:
+        return None, "none"
+    try:
+        rec = json.load(open(cands[-1])).get(kernel, {})
+        return rec.get("hbm_bytes"), os.path.basename(cands[-1])
+    except (OSError, ValueError):
+        return None, "unreadable"
 
 
 def cpu_baseline(spec, weights, xb, lb, ratio, n_windows):
