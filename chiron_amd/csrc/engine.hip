@@ -187,6 +187,7 @@ struct chiron_engine {
   std::vector<BlockPlan> blocks;
   std::vector<LstmPlan> lstm;
   float *fc_w = nullptr, *fc_b = nullptr, *fc_wc = nullptr, *fc_bc = nullptr;
+  float* zero_page = nullptr;  // 256 B of zeros: DMA source for padded rows / K tails (gemm.hip)
   std::vector<Slot> slots;
   std::vector<void*> owned;  // device allocations freed on destroy
   bool profiling = false;
@@ -478,7 +479,8 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->K = desc->classes;
   e->maxB = opts->max_batch;
   e->BP = roundup(opts->max_batch, 16);
-  st = build_plans(e, weights);
+  st = dev_alloc(e, (void**)&e->zero_page, 256, true);
+  if (st == CHIRON_OK) st = build_plans(e, weights);
   if (st == CHIRON_OK) {
     e->slots.resize(e->opts.n_slots);
     for (Slot& s : e->slots)
@@ -545,15 +547,16 @@ struct Prof {
   }
 };
 
-static void init_gemm(GemmParams* g, const ConvGemmPlan& w, int B, int BP) {
+static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan& w, int B) {
   memset(g, 0, sizeof(*g));
   g->B = B;
-  g->BP = BP;
+  g->BP = e->BP;
   g->N = w.N;
   g->K = w.K;
   g->Wt = w.Wt;
   g->shift = w.shift;
   g->z_dirs_total = 2;
+  g->zero_page = e->zero_page;
 }
 
 static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
@@ -572,7 +575,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
     GemmParams g;
     if (b.lift) {
       // conv2b over the lifted signal: A(m, tap*C + c) = relu(sig*a[c] + b[c])
-      init_gemm(&g, b.gb, B, e->BP);
+      init_gemm(&g, e, b.gb, B);
       g.M = B * b.t_out;
       g.T_out = b.t_out;
       g.nseg = b.k;
@@ -589,7 +592,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
         launch_gemm(g, s->stream);
       }
       // conv2c + lifted branch1 + ReLU
-      init_gemm(&g, b.gc, B, e->BP);
+      init_gemm(&g, e, b.gc, B);
       g.M = B * b.t_out;
       g.T_out = b.t_out;
       g.nseg = 1;
@@ -610,7 +613,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
     } else {
       const int cip = roundup(b.c_in, GEMM_BK);
       // conv2a
-      init_gemm(&g, b.ga, B, e->BP);
+      init_gemm(&g, e, b.ga, B);
       g.M = B * b.t_in;
       g.T_out = b.t_in;
       g.nseg = 1;
@@ -623,7 +626,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
         launch_gemm(g, s->stream);
       }
       // conv2b
-      init_gemm(&g, b.gb, B, e->BP);
+      init_gemm(&g, e, b.gb, B);
       g.M = B * b.t_out;
       g.T_out = b.t_out;
       g.nseg = b.k;
@@ -636,7 +639,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
         launch_gemm(g, s->stream);
       }
       // conv2c + branch1/conv1 fused along K, + ReLU
-      init_gemm(&g, b.gc, B, e->BP);
+      init_gemm(&g, e, b.gc, B);
       g.M = B * b.t_out;
       g.T_out = b.t_out;
       g.nseg = 2;
@@ -666,7 +669,7 @@ static void run_rnn(chiron_engine* e, Slot* s, int B) {
     float* outbuf = s->lasth[l & 1];
     for (int pj = 0; pj < lp.nproj; ++pj) {
       GemmParams g;
-      init_gemm(&g, lp.proj[pj], B, BP);
+      init_gemm(&g, e, lp.proj[pj], B);
       g.M = T * BP;
       g.T_out = T;
       g.m_time_major = 1;

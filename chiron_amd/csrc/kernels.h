@@ -64,6 +64,7 @@ struct GemmParams {
   int z_ndir;      // out_mode 1: directions interleaved in N (N = z_ndir * z_tiles * 16)
   int z_dir0;      // out_mode 1: first direction index written by this launch
   int z_dirs_total;  // out_mode 1: directions in the z buffer (2)
+  const float* zero_page;  // >= 256 B of zeros: DMA source of padded rows / K tails
 };
 
 void launch_gemm(const GemmParams& p, hipStream_t stream);
