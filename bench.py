@@ -7,8 +7,8 @@ data-path collective ("scaling": "weak": every rank runs K batches of 1100 windo
 
 A step = one pass of the hot path over one batch of 1100 windows whose signal is already resident
 in HBM: CNN -> 3x BiLSTM -> FC -> greedy CTC -> SparseTensor on device, decoded tensor copied to
-the host, per-read regroup + glue overlap-consensus vote on the host.  Two batches are kept in
-flight (two engine slots / HIP streams).
+the host, per-read regroup + glue overlap-consensus vote on the host.  Three batches are kept in
+flight (three engine slots / HIP streams; --slots).
 
 value = signal-normalised kbases/s = windows * jump / (4000 Hz / 450 b/s) / seconds / 1000
 (SURVEY.md 8d (i)); decoded consensus bases/s with the synthetic weights is reported in "extra".
@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--slots", type=int, default=2, help="batches in flight (engine slots / HIP streams)")
+    ap.add_argument("--slots", type=int, default=3, help="batches in flight (engine slots / HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
     args = ap.parse_args()

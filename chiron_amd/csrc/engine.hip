@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -183,7 +184,7 @@ struct chiron_engine {
   chiron_engine_opts opts;
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
-  int hpz = 0, tiles = 0;
+  int lstm_rows = 4;   // batch rows per recurrence workgroup (4, 8 or 16)
   std::vector<BlockPlan> blocks;
   std::vector<LstmPlan> lstm;
   float *fc_w = nullptr, *fc_b = nullptr, *fc_wc = nullptr, *fc_bc = nullptr;
@@ -337,12 +338,10 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
   e->T = t;
   e->C = d.blocks[d.n_blocks - 1].out_channels;
 
-  // ---- LSTM layers
+  // ---- LSTM layers.  z column n of a direction: wave = n/64, gate = (n%64)/16, unit = 16*wave + n%16
+  // (the accumulator-fragment order of lstm.hip).
   const int H = d.hidden;
-  e->hpz = roundup(H, 16);
-  e->tiles = 4 * (e->hpz / 16);
-  const int zc = e->tiles * 16;  // z columns per direction
-  const int KS = lstm_ksteps(100);  // the recurrence kernel is instantiated for 25 k-steps
+  const int zc = LSTM_ZCOLS;
   for (int l = 0; l < d.rnn_layers; ++l) {
     LstmPlan lp;
     lp.in_w = lstm_in_width(&d, l);
@@ -366,7 +365,7 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       for (int n = 0; n < N; ++n) {
         const int dir = split ? pj : n / zc;
         const int nl = n % zc;
-        const int g = nl / e->hpz, unit = nl % e->hpz;
+        const int g = (nl % 64) / 16, unit = 16 * (nl / 64) + nl % 16;
         if (unit >= H) continue;
         for (int k = 0; k < lp.in_w; ++k) Wt[(size_t)n * Kp + k] = kern[dir][(size_t)k * 4 * H + g * H + unit];
         // forget_bias = 1.0 (TF LSTMCell default; Add(+1.0) const in the .meta while-body) folded here
@@ -374,20 +373,17 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       }
       if ((st = upload_gemm(e, &lp.proj[pj], Wt, sh, N, Npad, Kp))) return st;
     }
-    // recurrent weights in MFMA B-fragment order: [dir][wave][ti = ubl*4 + g][s][lane]
-    std::vector<float> wf((size_t)2 * LSTM_WAVES * 8 * KS * 64, 0.f);
+    // recurrent weights in MFMA B-operand order: [dir][wave][k][lane], lane = gate*16 + (unit & 15)
+    std::vector<float> wf((size_t)2 * LSTM_NW * LSTM_K * 64, 0.f);
     for (int dir = 0; dir < 2; ++dir)
-      for (int wv = 0; wv < LSTM_WAVES; ++wv)
-        for (int ubl = 0; ubl < 2; ++ubl)
-          for (int g = 0; g < 4; ++g)
-            for (int s = 0; s < KS; ++s)
-              for (int lane = 0; lane < 64; ++lane) {
-                const int k = 4 * s + (lane >> 4);
-                const int unit = (wv * 2 + ubl) * 16 + (lane & 15);
-                float v = 0.f;
-                if (k < H && unit < H) v = kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + unit];
-                wf[((((size_t)dir * LSTM_WAVES + wv) * 8 + ubl * 4 + g) * KS + s) * 64 + lane] = v;
-              }
+      for (int wv = 0; wv < LSTM_NW; ++wv)
+        for (int k = 0; k < LSTM_K; ++k)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, unit = 16 * wv + (lane & 15);
+            float v = 0.f;
+            if (k < H && unit < H) v = kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + unit];
+            wf[(((size_t)dir * LSTM_NW + wv) * LSTM_K + k) * 64 + lane] = v;
+          }
     if ((st = dev_upload(e, &lp.wfrag, wf))) return st;
     e->lstm.push_back(lp);
   }
@@ -424,7 +420,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   if ((st = dev_alloc(e, (void**)&s->seq, BP * 4, true))) return st;
   for (int i = 0; i < 3; ++i)
     if ((st = dev_alloc(e, (void**)&s->act[i], B * tmax * cmax * 4, false))) return st;
-  if ((st = dev_alloc(e, (void**)&s->z, T * (BP / 16) * 2 * e->tiles * 256 * 4, true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->z, T * BP * 2 * LSTM_ZCOLS * 4, true))) return st;
   for (int i = 0; i < 2; ++i)
     if ((st = dev_alloc(e, (void**)&s->lasth[i], T * BP * 2 * H * 4, true))) return st;
   if ((st = dev_alloc(e, (void**)&s->logits, B * T * K * 4, false))) return st;
@@ -479,6 +475,11 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->K = desc->classes;
   e->maxB = opts->max_batch;
   e->BP = roundup(opts->max_batch, 16);
+  {
+    const char* ev = getenv("CHIRON_LSTM_ROWS");  // tuning knob; results do not depend on it
+    const int r = ev ? atoi(ev) : 4;
+    e->lstm_rows = (r == 8 || r == 16) ? r : 4;
+  }
   st = dev_alloc(e, (void**)&e->zero_page, 256, true);
   if (st == CHIRON_OK) st = build_plans(e, weights);
   if (st == CHIRON_OK) {
@@ -662,7 +663,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
 static void run_rnn(chiron_engine* e, Slot* s, int B) {
   const float* fea = s->sig_used;
   const int T = e->T, H = e->H, BP = e->BP;
-  const int zc = e->tiles * 16;
+  const int zc = LSTM_ZCOLS;
   const float* prev = nullptr;
   for (size_t l = 0; l < e->lstm.size(); ++l) {
     const LstmPlan& lp = e->lstm[l];
@@ -683,7 +684,7 @@ static void run_rnn(chiron_engine* e, Slot* s, int B) {
         g.seg[0] = GemmSeg{prev, 2 * H, pj * H, H, Kp, T, 1, 0, 1};
       g.out = s->z;
       g.out_mode = 1;
-      g.z_tiles = e->tiles;
+      g.z_cols = LSTM_ZCOLS;
       g.z_ndir = lp.nproj == 1 ? 2 : 1;
       g.z_dir0 = lp.nproj == 1 ? 0 : pj;
       const double ndir = lp.nproj == 1 ? 2.0 : 1.0;
@@ -699,9 +700,8 @@ static void run_rnn(chiron_engine* e, Slot* s, int B) {
     r.B = B;
     r.BP = BP;
     r.H = H;
-    r.tiles = e->tiles;
-    r.hpz = e->hpz;
     r.ndir = 2;
+    r.rows_per_wg = e->lstm_rows;
     {
       Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H, 4.0 * B * T * 2.0 * (zc + H));
       launch_lstm(r, s->stream);

@@ -70,8 +70,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       const int n = n0 + wn * 64 + ni * 32 + li;
       if (n >= p.N) continue;
       const float sh = p.shift[n];
-      const int nbt = p.BP >> 4;
-      const int zcols = p.z_tiles * 16;
+      const int nb4 = p.BP >> 2;
+      const int zcols = p.z_cols;
       const int dir = p.z_dir0 + n / zcols;
       const int nl = n % zcols;
 #pragma unroll
@@ -81,12 +81,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           const int mq = m0 + wm * 64 + mi * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows
           if (mq >= p.M) continue;
           const int t = mq / p.BP;
-          const int b = mq - t * p.BP;  // multiple of 4
-          const long tile = (((long)t * nbt + (b >> 4)) * p.z_dirs_total + dir) * p.z_tiles + (nl >> 4);
+          const int b = mq - t * p.BP;  // multiple of 4: one 4-row group of lstm.hip
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r] + sh;
-          *reinterpret_cast<f32x4*>(p.out + tile * 256 + ((b & 15) >> 2) * 64 + (nl & 15) * 4) = v;
+          *reinterpret_cast<f32x4*>(p.out + ((((long)t * nb4 + (b >> 2)) * p.z_dirs_total + dir) * zcols + nl) * 4) = v;
         }
       }
     }

@@ -60,8 +60,8 @@ struct GemmParams {
   float* out;
   int ldo;         // row stride (out_mode 0)
   int out_mode;    // 0: out[m*ldo + n];  1: LSTM z fragment layout (see lstm.hip)
-  int z_tiles;     // out_mode 1: 16-column tiles per direction (4 gates * HP/16)
-  int z_ndir;      // out_mode 1: directions interleaved in N (N = z_ndir * z_tiles * 16)
+  int z_cols;      // out_mode 1: z columns per direction (LSTM_ZCOLS)
+  int z_ndir;      // out_mode 1: directions interleaved in N (N = z_ndir * z_cols)
   int z_dir0;      // out_mode 1: first direction index written by this launch
   int z_dirs_total;  // out_mode 1: directions in the z buffer (2)
   const float* zero_page;  // >= 256 B of zeros: DMA source of padded rows / K tails
@@ -70,25 +70,22 @@ struct GemmParams {
 void launch_gemm(const GemmParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
-// LSTM recurrence (lstm.hip): one workgroup = 16 batch rows x one direction x all T steps.
+// LSTM recurrence (lstm.hip): one workgroup = 4*NG batch rows x one direction x all T steps.
 // ---------------------------------------------------------------------------------------------
-constexpr int LSTM_ROWS = 16;     // batch rows per workgroup (one 16x16x4 MFMA tile in M)
-constexpr int LSTM_WAVES = 4;
-constexpr int LSTM_UB_PER_WAVE = 2;  // 16-unit blocks owned by one wave
-constexpr int LSTM_HP = 128;      // hidden padded: LSTM_WAVES*LSTM_UB_PER_WAVE*16 (z stores HPZ)
+constexpr int LSTM_K = 100;      // hidden size the kernel is built for (rnn.py:23 hidden_num=100)
+constexpr int LSTM_NW = 7;       // waves per workgroup; wave w owns hidden units [16w, 16w+16)
+constexpr int LSTM_ZCOLS = 64 * LSTM_NW;  // z columns per direction: wave*64 + gate*16 + (unit & 15)
 
 struct LstmParams {
-  const float* z;        // [T][NBT][ndir][tiles][4 rowgroups][16 cols][4 regs]  (x-projection + bias)
-  const float* wfrag;    // [ndir][LSTM_WAVES][8 tiles][KSTEPS][64 lanes] recurrent weights, fragment order
+  const float* z;        // [T][BP/4][ndir][LSTM_ZCOLS][4 rows]  x-projection + bias, MFMA fragment order
+  const float* wfrag;    // [ndir][LSTM_NW][LSTM_K][64 lanes] recurrent weights, fragment order
   const int32_t* seq_len;  // [BP] (0 for padded rows)
   float* out;            // lasth [T][BP][ndir*H] time major
-  int T, B, BP, H;       // H = hidden (<= 100 .. 128)
-  int tiles;             // 16-column tiles per direction in z
-  int hpz;               // padded hidden in z (multiple of 16)
+  int T, B, BP, H;
   int ndir;              // 2
+  int rows_per_wg;       // 4, 8 or 16
 };
 void launch_lstm(const LstmParams& p, hipStream_t stream);
-int lstm_ksteps(int H);
 
 // ---------------------------------------------------------------------------------------------
 // FC head + CTC (head_ctc.hip)

@@ -2,14 +2,21 @@
 // sequence_length (chiron/rnn.py:49-65 / :140-145; op composition recorded in the shipped .meta
 // graphs) as ONE persistent launch per layer.
 //
-//   workgroup = 16 batch rows x 1 direction, resident for all T steps (rows never interact, so no
-//   grid-wide sync exists).  4 waves, one per SIMD; wave w owns hidden units [32w, 32w+32) for all
-//   four gates = 8 accumulator tiles of v_mfma_f32_16x16x4_f32 (M = batch rows, N = units,
-//   K = previous hidden).  The recurrent weights W_hh (100x400 fp32 = 160 KB, the size of the whole
-//   LDS) live in VGPRs for the entire sequence: 8 tiles x 25 k-steps = 200 registers per lane.
-//   h_{t-1} is exchanged through a double-buffered 16x100 LDS tile (one barrier per step);
-//   the x-projection z_t (+bias, forget bias folded in) was produced by gemm.hip directly in this
-//   kernel's accumulator-fragment order, so each tile is one coalesced 16-byte load per lane.
+//   workgroup = 4*NG batch rows x 1 direction, resident for all T steps (rows never interact, so no
+//   grid-wide sync exists).  7 waves; wave w owns hidden units [16w, 16w+16) for all four gates = 64
+//   matrix columns = exactly the N extent of ONE v_mfma_f32_4x4x1_16B_f32 (16 blocks of a 4x4 outer
+//   product: M = 4 batch rows, N = 64 columns, K = 1).  Its slice of W_hh lives in VGPRs for the whole
+//   sequence (100 registers per lane; W_hh = 160 KB fp32 = the entire LDS, spread over 7 register files).
+//   The 4-row MFMA shape is what lets B = 1100 fill the chip: 16-row tiles give 138 workgroups for 256
+//   CUs, 4-row groups give 550 half-CU workgroups; the instruction runs at the same 64 FLOP/clk/SIMD.
+//   (v_mfma_f32_* shares the fp32 VALU datapath -- tools/ubench/barrier_mfma.hip -- so the gate math can
+//   not hide behind it; what counts is total issue time, and this layout needs ONE cell per lane.)
+//
+//   per step and row group:  acc[4 rows] (lane = gate*16 + unit)  <-  h_{t-1} . W_hh      100 MFMAs
+//                            + z_t (x-projection, produced by gemm.hip in exactly this fragment order)
+//                            4x4 transpose through LDS: lane (row, unit) gets i, j, f, o of its cell
+//                            c = sig(f)*c + sig(i)*tanh(j);  h = sig(o)*tanh(c)   (forget bias folded in z)
+//   h is exchanged through a double-buffered [4 rows][100] LDS tile per group, one barrier per step.
 //   Masking: rows with t >= seq_len emit 0 and carry (c,h); the backward direction walks
 //   t = seq_len-1-s per row (tf.reverse_sequence folded into index arithmetic, no copy).
 #include "kernels.h"
@@ -22,7 +29,7 @@ namespace chiron {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int HS = 102;  // LDS row stride of the h tile: rows*6 mod 32 distinct -> conflict-free reads
+constexpr int HS4 = 104;  // LDS row stride (floats) of an h row: 16-byte aligned rows for ds_read_b128
 
 __device__ __forceinline__ float fast_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
@@ -32,149 +39,157 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f), 1.0f);
 }
 
-template <int KS>
-__global__ __launch_bounds__(256, 1) void lstm_kernel(const LstmParams p) {
-  __shared__ float hbuf[2][LSTM_ROWS * HS];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int col = lane & 15;
-  const int rg = lane >> 4;  // row group: rows rg*4 .. rg*4+3
-  const int dir = blockIdx.x % p.ndir;
-  const int btile = blockIdx.x / p.ndir;
-  const int b0 = btile * LSTM_ROWS;
-  const int nbt = p.BP / LSTM_ROWS;
-  const int ubz = p.hpz >> 4;  // unit blocks present in z
-
-  // ---- recurrent weights into registers (fragment order prepared on the host)
-  float w[8][KS];
-  {
-    const float* wf = p.wfrag + (((long)dir * LSTM_WAVES + wave) * 8) * KS * 64 + lane;
-#pragma unroll
-    for (int ti = 0; ti < 8; ++ti)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) w[ti][s] = wf[(ti * KS + s) * 64];
-  }
-
-  for (int i = tid; i < 2 * LSTM_ROWS * HS; i += 256) (&hbuf[0][0])[i] = 0.f;
-
-  int len[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) len[r] = p.seq_len[b0 + rg * 4 + r];
-  int maxlen = max(max(len[0], len[1]), max(len[2], len[3]));
-  int minlen = min(min(len[0], len[1]), min(len[2], len[3]));
-  maxlen = max(maxlen, __shfl_xor(maxlen, 16));
-  maxlen = max(maxlen, __shfl_xor(maxlen, 32));
-  minlen = min(minlen, __shfl_xor(minlen, 16));
-  minlen = min(minlen, __shfl_xor(minlen, 32));
-  maxlen = min(maxlen, p.T);
-  const bool uniform = (minlen == maxlen) || dir == 0;  // all rows share t at every active step
-
-  float c[2][4], hreg[2][4];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c[u][r] = hreg[u][r] = 0.f;
-
+template <int NG, bool UNIFORM>
+__device__ __forceinline__ void lstm_loop(const LstmParams& p, const float (&w)[LSTM_K], float* hbuf, float* tbuf,
+                                          const int (&len4)[NG][4], const int (&lenr)[NG], int maxlen, int dir, int g0,
+                                          int wave, int lane) {
+  const int unit = wave * 16 + (lane & 15);
+  const int row = lane >> 4;         // after the transpose: this lane's batch row within the group
+  const bool live = unit < p.H;
+  const int nb4 = p.BP >> 2;
   const int outw = p.ndir * p.H;
-  __syncthreads();
+  const long zstep = (long)nb4 * p.ndir * LSTM_ZCOLS * 4;  // floats between consecutive t
+  const float* zb = p.z + (((long)g0 * p.ndir + dir) * LSTM_ZCOLS + wave * 64 + lane) * 4;
+  const long zgrp = (long)p.ndir * LSTM_ZCOLS * 4;         // floats between consecutive row groups
+  float* tw = tbuf + wave * NG * 256;                      // this wave's transpose scratch
+
+  float c[NG], hprev[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) c[g] = hprev[g] = 0.f;
 
   int cur = 0;
   for (int s = 0; s < maxlen; ++s) {
-    // ---- z_t loads (consumed after the MFMA chain; their latency hides behind it)
-    f32x4 z[8];
-    int tr[4];
-    bool act[4];
+    // ---- z_t for the 4 rows of each group (one 16-byte load per lane when t is uniform)
+    f32x4 z[NG];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      act[r] = s < len[r];
-      tr[r] = dir == 0 ? s : (act[r] ? len[r] - 1 - s : 0);
-    }
+    for (int g = 0; g < NG; ++g) {
+      if (UNIFORM) {
+        const int t = dir == 0 ? s : maxlen - 1 - s;
+        z[g] = *reinterpret_cast<const f32x4*>(zb + t * zstep + g * zgrp);
+      } else {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int ub = wave * 2 + u;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ub < ubz) {
-          const int tile = g * ubz + ub;
-          if (uniform) {
-            const int t = dir == 0 ? s : maxlen - 1 - s;
-            const long base = ((((long)t * nbt + btile) * p.ndir + dir) * p.tiles + tile) * 256;
-            v = *reinterpret_cast<const f32x4*>(p.z + base + rg * 64 + col * 4);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const long base = ((((long)tr[r] * nbt + btile) * p.ndir + dir) * p.tiles + tile) * 256;
-              v[r] = p.z[base + rg * 64 + col * 4 + r];
-            }
-          }
+        for (int r = 0; r < 4; ++r) {
+          const bool a = s < len4[g][r];
+          const int t = dir == 0 ? s : (a ? len4[g][r] - 1 - s : 0);
+          z[g][r] = zb[t * zstep + g * zgrp + r];
         }
-        z[u * 4 + g] = v;
       }
     }
-
-    // ---- h_{t-1} A fragments: A[i = lane&15][k = 4s + (lane>>4)]
-    float a[KS];
-    const float* hb = &hbuf[cur][col * HS + rg];
+    // ---- acc = h_{s-1} . W_hh : A[block][i] = h[row i][k] for every block, B = this lane's column of W_hh
+    constexpr int NA = NG == 1 ? 2 : 1;  // a lone group alternates two accumulators (dependent MFMA = 12 cycles)
+    f32x4 acc[NG][NA];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) a[k] = hb[4 * k];
-
-    f32x4 acc[8];
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int ti = 0; ti < 8; ++ti) acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < NA; ++a) acc[g][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* hb = hbuf + cur * (NG * 4 * HS4) + (lane & 3) * HS4;
 #pragma unroll
-    for (int k = 0; k < KS; ++k)
+    for (int q = 0; q < LSTM_K / 4; ++q) {
+      f32x4 a4[NG];
 #pragma unroll
-      for (int ti = 0; ti < 8; ++ti)
-        acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], w[ti][k], acc[ti], 0, 0, 0);
-
-    // ---- gates (lane-local: accumulator (row, unit) coincides for the four gate tiles)
-    float* hn = &hbuf[cur ^ 1][0];
+      for (int g = 0; g < NG; ++g) a4[g] = *reinterpret_cast<const f32x4*>(hb + g * 4 * HS4 + 4 * q);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int unit = (wave * 2 + u) * 16 + col;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float gi = acc[u * 4 + 0][r] + z[u * 4 + 0][r];
-        const float gj = acc[u * 4 + 1][r] + z[u * 4 + 1][r];
-        const float gf = acc[u * 4 + 2][r] + z[u * 4 + 2][r];
-        const float go = acc[u * 4 + 3][r] + z[u * 4 + 3][r];
-        const float cn = fmaf(fast_sigmoid(gf), c[u][r], fast_sigmoid(gi) * fast_tanh(gj));
-        const float hnew = fast_sigmoid(go) * fast_tanh(cn);
-        if (act[r]) {
-          c[u][r] = cn;
-          hreg[u][r] = hnew;
-        }
-        if (unit < p.H) {
-          const int row = rg * 4 + r;
-          hn[row * HS + unit] = hreg[u][r];
-          const int to = act[r] ? tr[r] : s;
-          p.out[((long)to * p.BP + b0 + row) * outw + dir * p.H + unit] = act[r] ? hnew : 0.f;
-        }
+        for (int g = 0; g < NG; ++g)
+          acc[g][(q * 4 + j) % NA] =
+              __builtin_amdgcn_mfma_f32_4x4x1f32(a4[g][j], w[4 * q + j], acc[g][(q * 4 + j) % NA], 0, 0, 0);
+    }
+    // ---- gates: transpose (lane = gate*16+unit, reg = row) -> (lane = row*16+unit, reg = gate)
+    float* hn = hbuf + (cur ^ 1) * (NG * 4 * HS4);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      f32x4 v = acc[g][0];
+      if (NA == 2) v += acc[g][NA - 1];
+      v += z[g];
+      float* ts = tw + g * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ts[(r * 16 + (lane & 15)) * 4 + (lane >> 4)] = v[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(tw + g * 256 + lane * 4);  // i, j, f, o of (row, unit)
+      const bool act = UNIFORM ? true : (s < lenr[g]);
+      const float cn = fmaf(fast_sigmoid(q[2]), c[g], fast_sigmoid(q[0]) * fast_tanh(q[1]));
+      const float hnew = fast_sigmoid(q[3]) * fast_tanh(cn);
+      c[g] = act ? cn : c[g];
+      hprev[g] = act ? hnew : hprev[g];
+      if (live) {
+        hn[(g * 4 + row) * HS4 + unit] = hprev[g];
+        const int to = dir == 0 ? s : (UNIFORM ? maxlen - 1 - s : (act ? lenr[g] - 1 - s : s));
+        p.out[((long)to * p.BP + (g0 + g) * 4 + row) * outw + dir * p.H + unit] = act ? hnew : 0.f;
       }
     }
     cur ^= 1;
     __syncthreads();
   }
+}
 
-  // ---- frames past the longest row of this tile read back as zeros (dynamic_rnn semantics)
+template <int NG>
+__global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(const LstmParams p) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2 * NG * 4 * HS4];
+  __shared__ __attribute__((aligned(16))) float tbuf[LSTM_NW * NG * 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x % p.ndir;
+  const int g0 = (blockIdx.x / p.ndir) * NG;  // first 4-row group of this workgroup
+
+  // ---- this wave's 64 columns of the recurrent weights (fragment order prepared on the host)
+  float w[LSTM_K];
+  {
+    const float* wf = p.wfrag + ((long)dir * LSTM_NW + wave) * LSTM_K * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < LSTM_K; ++k) w[k] = wf[k * 64];
+  }
+  for (int i = tid; i < 2 * NG * 4 * HS4; i += 64 * LSTM_NW) hbuf[i] = 0.f;
+
+  int len4[NG][4], lenr[NG];
+  int maxlen = 0, minlen = 1 << 30;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      len4[g][r] = min(p.seq_len[(g0 + g) * 4 + r], p.T);
+      maxlen = max(maxlen, len4[g][r]);
+      minlen = min(minlen, len4[g][r]);
+    }
+    lenr[g] = len4[g][0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) lenr[g] = (lane >> 4) == r ? len4[g][r] : lenr[g];
+  }
+  __syncthreads();
+
+  if (minlen == maxlen)
+    lstm_loop<NG, true>(p, w, hbuf, tbuf, len4, lenr, maxlen, dir, g0, wave, lane);
+  else
+    lstm_loop<NG, false>(p, w, hbuf, tbuf, len4, lenr, maxlen, dir, g0, wave, lane);
+
+  // ---- frames past the longest row of this workgroup read back as zeros (dynamic_rnn semantics)
+  const int outw = p.ndir * p.H;
   for (int s = maxlen; s < p.T; ++s) {
-    for (int i = tid; i < LSTM_ROWS * p.H; i += 256) {
+    for (int i = tid; i < NG * 4 * p.H; i += 64 * LSTM_NW) {
       const int row = i / p.H;
       const int unit = i - row * p.H;
-      p.out[((long)s * p.BP + b0 + row) * outw + dir * p.H + unit] = 0.f;
+      p.out[((long)s * p.BP + g0 * 4 + row) * outw + dir * p.H + unit] = 0.f;
     }
   }
 }
 
-int lstm_ksteps(int H) { return (H + 3) / 4; }
-
 void launch_lstm(const LstmParams& p, hipStream_t stream) {
-  const int grid = (p.BP / LSTM_ROWS) * p.ndir;
   // hidden = 100 is the only size the reference's shipped models use (rnn.py:23 hidden_num=100)
-  hipLaunchKernelGGL(lstm_kernel<25>, dim3(grid), dim3(256), 0, stream, p);
+  const int groups = p.BP / 4;
+  const int ng = p.rows_per_wg / 4;
+  const dim3 block(64 * LSTM_NW);
+  if (ng == 1)
+    hipLaunchKernelGGL(lstm_kernel<1>, dim3(groups * p.ndir), block, 0, stream, p);
+  else if (ng == 2)
+    hipLaunchKernelGGL(lstm_kernel<2>, dim3(groups / 2 * p.ndir), block, 0, stream, p);
+  else
+    hipLaunchKernelGGL(lstm_kernel<4>, dim3(groups / 4 * p.ndir), block, 0, stream, p);
 }
 
 }  // namespace chiron
