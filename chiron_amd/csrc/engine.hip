@@ -492,7 +492,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     chiron_engine_destroy(e);
     return st;
   }
-  e->prof_names = {"conv_gemm", "lstm_proj_gemm", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob"};
+  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res"};
   *out = e;
   return CHIRON_OK;
 }
@@ -525,7 +525,7 @@ extern "C" chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out
 // ----------------------------------------------------------------------------------------------
 // launch sequence
 // ----------------------------------------------------------------------------------------------
-enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB };
+enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES };
 
 struct Prof {
   chiron_engine* e;
@@ -589,7 +589,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.out = bufB;
       g.ldo = b.c;
       {
-        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * b.t_out * b.c);
+        Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * b.t_out * b.c);
         launch_gemm(g, s->stream);
       }
       // conv2c + lifted branch1 + ReLU
@@ -606,7 +606,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.out = bufA;
       g.ldo = b.c;
       {
-        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.c * b.c, 8.0 * B * b.t_out * b.c);
+        Prof pr(e, s, PN_RES, 2.0 * B * b.t_out * (double)b.c * b.c, 8.0 * B * b.t_out * b.c);
         launch_gemm(g, s->stream);
       }
       x = bufA;

@@ -13,7 +13,9 @@ from collections import defaultdict
 
 def family(name):
     n = name.split("(")[0]
-    for key in ("gemm_f32_kernel", "lstm_kernel", "fc_kernel", "greedy_kernel", "beam_kernel", "scan_kernel", "scatter_kernel"):
+    if "gemm_f32_dma_kernel" in n or "gemm_f32_kernel" in n:
+        return n.replace("void ", "").replace("chiron::", "").strip()
+    for key in ("lstm_kernel", "fc_kernel", "greedy_kernel", "beam_kernel", "scan_kernel", "scatter_kernel"):
         if key in n:
             return key
     return None
