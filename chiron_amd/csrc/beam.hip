@@ -20,6 +20,8 @@
 //   1 + beam*T nodes (only leaves that survive a frame are materialised).
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace chiron {
 
 constexpr int BEAM_MAX = 256;
@@ -290,6 +292,311 @@ __global__ __launch_bounds__(64) void beam_kernel(const BeamParams p, int node_c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// beam <= 64: the whole beam lives in the registers of one wave (lane = beam slot).
+//
+// The generic kernel above pays an LDS (or HBM) round trip for every scalar the sequential grow walk
+// looks at.  Here the walk is event driven instead: in any state (top-N bottom, alive set, reset set) all
+// (branch, child) pairs are classified by every lane at once; only pairs that CHANGE the state (an insertion,
+// or TF's oldp.Reset() of a branch still waiting) are events, and the first event in TF's visiting order is
+// found with one ballot.  Events are applied one at a time with v_readlane / predicated moves, the bottom is
+// a DPP min + ballot.  The result is, by construction, the same sequence of state changes as the literal walk
+// (tests compare the two kernels bit for bit).
+//   node id -> beam slot is a byte table in LDS (1 + beam*T entries), so the per-frame trie look-ups
+//   (is my parent in the beam? which of my children are?) never leave the CU; the trie in HBM is write-mostly
+//   (read back only for a re-inserted node's child ids and for the final back-trace).
+//   Log-softmax of 64 frames at a time is held lane-distributed in registers and broadcast by v_readlane.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_min(float v) {
+  v = fminf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = fminf(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = fminf(v, dpp_f<0x141>(v));  // row_half_mirror
+  v = fminf(v, dpp_f<0x140>(v));  // row_mirror: every lane of a 16-lane row holds the row minimum
+  return fminf(fminf(rlf(v, 0), rlf(v, 16)), fminf(rlf(v, 32), rlf(v, 48)));
+}
+
+constexpr int B64_FIELDS = 11;
+
+__global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* scratch = reinterpret_cast<int*>(smem);                  // [B64_FIELDS][64] permutation buffer
+  int* chupd = scratch + B64_FIELDS * 64;                       // [64][4] child ids materialised this frame
+  unsigned char* slot_of = reinterpret_cast<unsigned char*>(chupd + 256);  // [node_cap], 255 = not in the beam
+
+  const int W = p.beam;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int K = p.K, T = p.T;
+  const int len = min(max(p.seq_len[b], 0), T);
+  BeamNode* nodes = reinterpret_cast<BeamNode*>(p.workspace) + (long)b * node_cap;
+  const float* lg = p.logits + (long)b * T * K;
+
+  // beam entry of this lane (valid for lane < nb), ranked by descending total
+  float e_tot = 0.f, e_blk = 0.f, e_lab = NEG_INF;
+  int e_node = 0, e_par = -1, e_lc = -1, e_depth = 0;
+  int e_ch[4] = {-1, -1, -1, -1};
+  if (lane == 0) {
+    BeamNode r;
+    r.parent = -1;
+    r.label = -1;
+    r.child[0] = r.child[1] = r.child[2] = r.child[3] = -1;
+    r.slot = 0;
+    r.depth = 0;
+    nodes[0] = r;
+    slot_of[0] = 0;
+  }
+  __syncthreads();
+  int nb = 1;
+  int n_nodes = 1;
+
+  for (int t0 = 0; t0 < len; t0 += 64) {
+    // ---- log-softmax of frames t0 .. t0+63, one frame per lane (TF normalises inside Step())
+    float lpk[CHIRON_KMAX];
+    {
+      const int t = min(t0 + lane, len - 1);
+      float x[CHIRON_KMAX];
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k) x[k] = k < K ? lg[t * K + k] : 0.f;
+      float mx = x[0];
+#pragma unroll
+      for (int k = 1; k < CHIRON_KMAX; ++k)
+        if (k < K) mx = fmaxf(mx, x[k]);
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k)
+        if (k < K) s += expf(x[k] - mx);
+      const float lse = logf(s);
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k) lpk[k] = (x[k] - mx) - lse;
+    }
+    const int tn = min(64, len - t0);
+    for (int tt = 0; tt < tn; ++tt) {
+      float logp[CHIRON_KMAX];
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k) logp[k] = rlf(lpk[k], tt);
+      const float lp_blank = logp[CHIRON_KMAX - 1];  // K == 5 (checked at launch)
+
+      // ---- P1: every entry extends itself; leaf registers start as the carried entries
+      const bool inb = lane < nb;
+      float l_tot = INFINITY, l_blk = NEG_INF, l_lab = NEG_INF;
+      int chs[4] = {-1, -1, -1, -1};
+      float cand[4];
+      {
+        const int lc = max(e_lc, 0);
+        const float lp_lc = lc == 0 ? logp[0] : lc == 1 ? logp[1] : lc == 2 ? logp[2] : logp[3];
+        int pslot = 255;
+        if (inb && e_par >= 0) pslot = slot_of[e_par];
+        const int src = pslot & 63;
+        const float p_tot = __shfl(e_tot, src), p_blk = __shfl(e_blk, src);
+        const int p_lc = __shfl(e_lc, src);
+        float n_label = e_lab;
+        if (e_par >= 0) {
+          if (pslot != 255) n_label = log_sum_exp(n_label, (e_lc == p_lc) ? p_blk : p_tot);
+          n_label += lp_lc;
+        }
+        const float n_blank = e_tot + lp_blank;
+        if (inb) {
+          l_tot = log_sum_exp(n_blank, n_label);
+          l_blk = n_blank;
+          l_lab = n_label;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (e_ch[c] >= 0) {
+              const int sl = slot_of[e_ch[c]];
+              chs[c] = sl == 255 ? -1 : sl;
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cand[c] = logp[c] + (c == e_lc ? e_blk : e_tot);
+      }
+      int l_node = e_node, l_par = -1, l_lc = e_lc, l_depth = e_depth, l_orig = inb ? lane : -1, l_pi = -1;
+
+      // ---- P2: grow new leaves, event by event, in TF's visiting order (branch-major, label-minor)
+      unsigned long long alive = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+      unsigned long long odead = 0ull;
+      int nL = nb;
+      int cur_i = -1, cur_c = -1;
+      float botv = NEG_INF;
+      int boti = 0;
+      bool full = nL >= W;
+      if (full) {
+        botv = wave_min(lane < nL ? l_tot : INFINITY);
+        boti = __builtin_ctzll(__ballot(lane < nL && l_tot == botv));
+      }
+      const bool has_old = inb && e_tot > NEG_INF;
+      while (true) {
+        const bool lane_cur = lane == cur_i;
+        const bool br = has_old && (lane_cur || (lane > cur_i && !((odead >> lane) & 1ull) && (!full || e_tot > botv)));
+        int evc = 4;
+        bool evins = false;
+        float sel_tot = 0.f;
+        int sel_node = -1, sel_co = -1;
+#pragma unroll
+        for (int c = 3; c >= 0; --c) {
+          const int co = chs[c];
+          const bool active = co >= 0 && ((alive >> co) & 1ull);
+          const float tot = cand[c];
+          const bool cnd = tot > NEG_INF && (!full || tot > botv);
+          // a rejected child that sits in the old beam loses its old probability; that only matters if it
+          // is a branch the walk has not reached yet
+          const bool rst = !cnd && co > lane && !((odead >> co) & 1ull);
+          const bool ev = br && (!lane_cur || c > cur_c) && !active && (cnd || rst);
+          if (ev) {
+            evc = c;
+            evins = cnd;
+            sel_tot = tot;
+            sel_node = e_ch[c];
+            sel_co = co;
+          }
+        }
+        const unsigned long long evm = __ballot(evc < 4);
+        if (evm == 0ull) break;
+        const int i = __builtin_ctzll(evm);
+        const int c = rli(evc, i);
+        if (rli((int)evins, i)) {
+          const float tot = rlf(sel_tot, i);
+          const int node = rli(sel_node, i);
+          const int pnode = rli(e_node, i);
+          const int depth = rli(e_depth, i) + 1;
+          int slot;
+          if (full) {  // the bottom leaves the search
+            slot = boti;
+            const int jo = rli(l_orig, slot);
+            if (jo >= 0) alive &= ~(1ull << jo);
+          } else {
+            slot = nL++;
+          }
+          if (lane == slot) {
+            l_tot = tot;
+            l_blk = NEG_INF;
+            l_lab = tot;
+            l_node = node;
+            l_par = pnode;
+            l_lc = c;
+            l_depth = depth;
+            l_orig = -1;
+            l_pi = i;
+          }
+          full = nL >= W;
+          if (full) {
+            botv = wave_min(lane < nL ? l_tot : INFINITY);
+            boti = __builtin_ctzll(__ballot(lane < nL && l_tot == botv));
+          }
+        } else {
+          odead |= 1ull << rli(sel_co, i);
+        }
+        cur_i = i;
+        cur_c = c;
+      }
+
+      // ---- P3: trie bookkeeping, rank the leaves (descending total), permute into rank order
+      if (inb && !((alive >> lane) & 1ull)) slot_of[e_node] = 255;
+      *reinterpret_cast<int4*>(chupd + 4 * lane) = make_int4(-1, -1, -1, -1);
+      const bool isleaf = lane < nL;
+      const bool inserted = isleaf && l_par >= 0;
+      const bool fresh = inserted && l_node < 0;
+      const unsigned long long fm = __ballot(fresh);
+      int f_ch[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) f_ch[c] = e_ch[c];
+      int f_par = e_par;
+      if (inserted) f_par = l_par;
+      if (fresh) {
+        l_node = n_nodes + __popcll(fm & ((1ull << lane) - 1ull));
+        BeamNode nd;
+        nd.parent = l_par;
+        nd.label = l_lc;
+        nd.child[0] = nd.child[1] = nd.child[2] = nd.child[3] = -1;
+        nd.slot = 0;
+        nd.depth = l_depth;
+        nodes[l_node] = nd;
+        nodes[l_par].child[l_lc] = l_node;
+        f_ch[0] = f_ch[1] = f_ch[2] = f_ch[3] = -1;
+      }
+      n_nodes += __popcll(fm);
+      __threadfence_block();
+      __syncthreads();
+      if (inserted && !fresh) {
+        // a node that was in the beam before (possibly evicted earlier in this very frame, after it had
+        // spawned children -- hence after the stores above): its children keep their identity
+        const int4 ch = *reinterpret_cast<const int4*>(nodes[l_node].child);
+        f_ch[0] = ch.x;
+        f_ch[1] = ch.y;
+        f_ch[2] = ch.z;
+        f_ch[3] = ch.w;
+      }
+      if (inserted) chupd[4 * l_pi + l_lc] = l_node;
+      __syncthreads();
+      if (isleaf && !inserted) {
+        const int4 u = *reinterpret_cast<const int4*>(chupd + 4 * lane);
+        f_ch[0] = u.x >= 0 ? u.x : f_ch[0];
+        f_ch[1] = u.y >= 0 ? u.y : f_ch[1];
+        f_ch[2] = u.z >= 0 ? u.z : f_ch[2];
+        f_ch[3] = u.w >= 0 ? u.w : f_ch[3];
+      }
+      int r = 0;
+      for (int k = 0; k < nL; ++k) {
+        const float tk = rlf(l_tot, k);
+        r += (tk > l_tot) || (tk == l_tot && k < lane);
+      }
+      if (isleaf) {
+        scratch[0 * 64 + r] = __float_as_int(l_tot);
+        scratch[1 * 64 + r] = __float_as_int(l_blk);
+        scratch[2 * 64 + r] = __float_as_int(l_lab);
+        scratch[3 * 64 + r] = l_node;
+        scratch[4 * 64 + r] = f_par;
+        scratch[5 * 64 + r] = l_lc;
+        scratch[6 * 64 + r] = l_depth;
+        scratch[7 * 64 + r] = f_ch[0];
+        scratch[8 * 64 + r] = f_ch[1];
+        scratch[9 * 64 + r] = f_ch[2];
+        scratch[10 * 64 + r] = f_ch[3];
+        slot_of[l_node] = (unsigned char)r;
+      }
+      __syncthreads();
+      nb = nL;
+      if (lane < nb) {
+        e_tot = __int_as_float(scratch[0 * 64 + lane]);
+        e_blk = __int_as_float(scratch[1 * 64 + lane]);
+        e_lab = __int_as_float(scratch[2 * 64 + lane]);
+        e_node = scratch[3 * 64 + lane];
+        e_par = scratch[4 * 64 + lane];
+        e_lc = scratch[5 * 64 + lane];
+        e_depth = scratch[6 * 64 + lane];
+        e_ch[0] = scratch[7 * 64 + lane];
+        e_ch[1] = scratch[8 * 64 + lane];
+        e_ch[2] = scratch[9 * 64 + lane];
+        e_ch[3] = scratch[10 * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- TopPaths(1): rank 0 is the leaf with the largest total; labels root -> leaf, no merging
+  if (lane == 0) {
+    int n = e_node;
+    uint8_t* out = p.labels + (long)b * T;
+    p.count[b] = e_depth;
+    p.log_prob[b] = e_tot;
+    while (n > 0) {
+      const BeamNode nd = nodes[n];
+      out[nd.depth - 1] = (uint8_t)nd.label;
+      n = nd.parent;
+    }
+  }
+}
+
+static size_t beam64_smem_bytes(int node_cap) {
+  return (size_t)(B64_FIELDS * 64 + 256) * 4 + (((size_t)node_cap + 15) & ~(size_t)15);
+}
+
 static size_t beam_smem_bytes(int W) { return (size_t)W * 4 * (5 + 7 + 8 + 2); }
 
 size_t beam_workspace_bytes(int B, int T, int beam) {
@@ -300,7 +607,13 @@ int launch_beam(const BeamParams& p, hipStream_t stream) {
   if (p.beam < 1 || p.beam > BEAM_MAX || p.K != 5) return -1;
   const int node_cap = 1 + p.beam * p.T;
   if ((size_t)p.B * node_cap * sizeof(BeamNode) > p.workspace_bytes) return -2;
-  hipLaunchKernelGGL(beam_kernel, dim3(p.B), dim3(64), beam_smem_bytes(p.beam), stream, p, node_cap);
+  // CHIRON_BEAM_GENERIC=1 forces the literal sequential kernel (the tests use it to cross-check the two)
+  const char* fg = getenv("CHIRON_BEAM_GENERIC");
+  const bool force_generic = fg && fg[0] == '1';
+  if (p.beam <= 64 && beam64_smem_bytes(node_cap) <= 30 * 1024 && !force_generic)
+    hipLaunchKernelGGL(beam64_kernel, dim3(p.B), dim3(64), beam64_smem_bytes(node_cap), stream, p, node_cap);
+  else
+    hipLaunchKernelGGL(beam_kernel, dim3(p.B), dim3(64), beam_smem_bytes(p.beam), stream, p, node_cap);
   return 0;
 }
 

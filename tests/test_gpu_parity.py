@@ -294,6 +294,35 @@ def test_decode_only_entry_brute_force_and_random(dna):
             _check_beam(r, lg, sl2, beam, B)
 
 
+def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
+    """beam <= 64 runs the event-driven in-register kernel (beam.hip beam64_kernel); CHIRON_BEAM_GENERIC=1
+    forces the literal sequential walk.  Both restate the same TF Step() order, so they must agree bit for
+    bit -- on flat posteriors (many insertions and evictions per frame, the order-dependent regime), on
+    peaked ones, and on ragged lengths."""
+    spec, w = dna
+    rng = np.random.RandomState(11)
+    B, T = 96, 400
+    flat = (rng.randn(B, T, 5) * 0.7).astype(np.float32)
+    peaked = (rng.randn(B, T, 5) * 4.0).astype(np.float32)
+    peaked[..., 4] += 3.0                                     # blank-dominated, like a trained model
+    quant = np.round(rng.randn(B, T, 5) * 2.0).astype(np.float32)   # exact ties everywhere
+    sl = rng.randint(0, T + 1, size=B).astype(np.int32)
+    sl[:4] = [0, 1, 2, T]
+    with ca.Engine(spec, w, max_batch=B, segment_len=400, max_beam=64) as eng:
+        for lg in (flat, peaked, quant):
+            for beam in (1, 2, 7, 30, 50, 64):
+                monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
+                a = eng.decode(lg, sl, beam_width=beam)
+                a = (a.decoded.indices.copy(), a.decoded.values.copy(), np.array(a.decoded.dense_shape), a.log_prob.copy())
+                monkeypatch.setenv("CHIRON_BEAM_GENERIC", "1")
+                g = eng.decode(lg, sl, beam_width=beam)
+                assert np.array_equal(a[0], g.decoded.indices), beam
+                assert np.array_equal(a[1], g.decoded.values), beam
+                assert np.array_equal(a[2], np.array(g.decoded.dense_shape)), beam
+                assert np.array_equal(a[3], g.log_prob), beam
+    monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
+
+
 def test_chiron_call_cli_on_fast5_folder(tmp_path):
     """BASELINE configs[0] plumbing: `chiron call` on a folder of fast5 files with model/DNA_default,
     batch=100, greedy.  The trained weights are stripped from the reference tree, so the CLI runs with

@@ -50,6 +50,10 @@ def run(name, spec, L, jump, B, beam, steps=6):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "batches":  # kernel time vs batch size (workgroup-count effects)
+        for B in [int(v) for v in sys.argv[2:]]:
+            run("DNA_default seg400 jump390 b%d greedy" % B, ca.dna_default_spec(), 400, 390, B, 0, steps=4)
+        sys.exit(0)
     run("RNA_default seg500 jump490 b400 beam50", ca.rna_default_spec(), 500, 490, 400, 50)
     run("DNA_default seg400 jump390 b1100 beam30", ca.dna_default_spec(), 400, 390, 1100, 30)
     run("DNA_default seg400 jump390 b1100 beam50", ca.dna_default_spec(), 400, 390, 1100, 50)
