@@ -6,6 +6,7 @@ not been built (python -c "import __graft_entry__ as g; g.build()").
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libchiron_amd.so")
@@ -81,6 +82,22 @@ class ChironError(RuntimeError):
         self.status = status
 
 
+def _init_torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own ROCm runtime.  Two HSA runtimes cannot both open the GPU from one
+    process: if libchiron_amd.so (linked against /opt/rocm) initialises HIP first, a later torch.cuda call
+    fails with "No HIP GPUs are available"; the other order is fine because the dynamic loader then resolves
+    our libamdhip64 dependency to the runtime torch already loaded.  So when torch is already imported (the
+    caller hands us device tensors, bench.py, torchrun sharding) make sure its runtime is up before dlopen."""
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:   # a torch build without GPU support is irrelevant to the engine
+        pass
+
+
 def load():
     """Load the HIP library.  Fails loudly when it is missing: no fallback exists."""
     global _lib
@@ -89,6 +106,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). chiron_amd has no CPU fallback." % LIB_PATH)
+    _init_torch_runtime_first()
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)

@@ -14,6 +14,8 @@
 //   unconditional from a clamped address and masked afterwards (no divergent branches in the loop).
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace chiron {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,7 +24,98 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDS_LD = GEMM_BK + 4;  // 36 floats: 16B-aligned rows, conflict-free b128 access
 constexpr int TILE_F = GEMM_BM * LDS_LD;
 
-template <bool ZOUT, bool RES>
+// (b, t) of the rows of one 128-row tile without a per-row integer division: the quotient of the tile's first
+// row is wave-uniform, every other row is at most two wrap-arounds away (inner >= 64).
+struct RowSplit {
+  int q0, r0, inner;  // m0 = q0 * inner + r0
+  __device__ __forceinline__ RowSplit(int m0, int inner_) : inner(inner_) {
+    q0 = m0 / inner_;
+    r0 = m0 - q0 * inner_;
+  }
+  __device__ __forceinline__ void split(int dm, int& q, int& r) const {  // row m0 + dm, 0 <= dm < 128
+    r = r0 + dm;
+    q = q0;
+    if (inner >= 64) {
+      if (r >= inner) { r -= inner; ++q; }
+      if (r >= inner) { r -= inner; ++q; }
+    } else {
+      const int e = r / inner;
+      q += e;
+      r -= e * inner;
+    }
+  }
+};
+
+// Epilogue of the DMA kernel for a tile that lies completely inside N: no per-store bounds checks or branches,
+// one base address per row (the stores use immediate offsets), ReLU as one v_med3 per value, shift already in
+// the accumulators.  ~100 VALU instructions per tile instead of ~350 -- they are all paid in matrix-pipe time.
+template <bool ZOUT, bool RES, bool RELU>
+__device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                                   int li, int kh) {
+  if (!ZOUT) {
+    const RowSplit rs(m0, p.T_out);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + li;
+      if (m >= p.M) continue;
+      float sv = 0.f;
+      if (RES) {
+        int b, t;
+        rs.split(wm * 64 + mi * 32 + li, b, t);
+        sv = p.sig[(long)b * p.L + (long)t * p.res_stride];
+      }
+      float* orow = p.out + (long)m * p.ldo + n0 + wn * 64 + 4 * kh;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r];
+          if (RES) {
+            const f32x4 ra4 = *reinterpret_cast<const f32x4*>(p.res_a + n0 + wn * 64 + ni * 32 + 8 * q + 4 * kh);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(sv, ra4[r], v[r]);
+          }
+          if (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, INFINITY);
+          }
+          *reinterpret_cast<f32x4*>(orow + ni * 32 + 8 * q) = v;
+        }
+      }
+    }
+  } else {
+    const RowSplit rs(m0, p.BP);
+    const int nb4 = p.BP >> 2;
+    const int zcols = p.z_cols;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int dm = wm * 64 + mi * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows: one 4-row group of lstm.hip
+        if (m0 + dm >= p.M) continue;
+        int t, b;
+        rs.split(dm, t, b);
+        float* og = p.out + (((long)t * nb4 + (b >> 2)) * p.z_dirs_total) * zcols * 4;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int n = n0 + wn * 64 + ni * 32 + li;
+          const int dir = p.z_dir0 + (n >= zcols ? 1 : 0);  // z_cols >= 128: a tile spans at most two directions
+          const int nl = n - (n >= zcols ? zcols : 0);
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r];
+          *reinterpret_cast<f32x4*>(og + ((long)dir * zcols + nl) * 4) = v;
+        }
+      }
+    }
+  }
+}
+
+// Stores LO <= idx < HI of the 16 16-byte stores a lane owns (idx = (outer*2 + inner)*4 + q): the DMA kernel
+// spreads one tile's stores over the first chunks of the next tile.
+template <bool ZOUT, bool RES, int LO = 0, int HI = 16, bool ADD_SHIFT = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
                                               int li, int kh) {
     // ---- epilogue.  32x32 accumulator layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -32,6 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   if (!ZOUT) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+      if (mi * 8 >= HI || mi * 8 + 8 <= LO) continue;
       const int m = m0 + wm * 64 + mi * 32 + li;
       if (m >= p.M) continue;
       float sv = 0.f;
@@ -45,12 +139,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if ((mi * 2 + ni) * 4 + q < LO || (mi * 2 + ni) * 4 + q >= HI) continue;
           const int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * kh;  // 4 consecutive columns
           if (n >= p.N) continue;
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
           f32x4 v;
+          if (ADD_SHIFT) {
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r] + sh[r];
+            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r] + sh[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r];
+          }
           if (RES) {
             const f32x4 ra4 = *reinterpret_cast<const f32x4*>(p.res_a + n);
 #pragma unroll
@@ -67,9 +167,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   } else {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
+      if (ni * 8 >= HI || ni * 8 + 8 <= LO) continue;
       const int n = n0 + wn * 64 + ni * 32 + li;
       if (n >= p.N) continue;
-      const float sh = p.shift[n];
+      const float sh = ADD_SHIFT ? p.shift[n] : 0.f;
       const int nb4 = p.BP >> 2;
       const int zcols = p.z_cols;
       const int dir = p.z_dir0 + n / zcols;
@@ -78,13 +179,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if ((ni * 2 + mi) * 4 + q < LO || (ni * 2 + mi) * 4 + q >= HI) continue;
           const int mq = m0 + wm * 64 + mi * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows
           if (mq >= p.M) continue;
           const int t = mq / p.BP;
           const int b = mq - t * p.BP;  // multiple of 4: one 4-row group of lstm.hip
           f32x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r] + sh;
+          for (int r = 0; r < 4; ++r) v[r] = ADD_SHIFT ? acc[mi][ni][4 * q + r] + sh : acc[mi][ni][4 * q + r];
           *reinterpret_cast<f32x4*>(p.out + ((((long)t * nb4 + (b >> 2)) * p.z_dirs_total + dir) * zcols + nl) * 4) = v;
         }
       }
@@ -321,13 +423,48 @@ typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 constexpr int DTILE_F = GEMM_BM * GEMM_BK;  // 4096 floats = 16 KB per operand tile
 
-template <bool ZOUT, bool RES>
+constexpr int DMA_MAX_N = 1024;  // output columns whose shift fits the LDS table
+constexpr int DMA_PAD_F = 256;  // floats in front of the tiles: the instruction offset (<= 896 B) is also
+                                 // added to the LDS address and is compensated in M0, which must stay >= 0
+
+struct DmaSrc {
+  const float* aptr[4];  // per piece: source of this lane's 16 bytes for chunk 0 of the current segment
+  const float* bptr[4];
+  bool aok[4];
+};
+
+// Issue one chunk.  The chunk index C inside the segment is a compile-time constant and travels in the
+// instruction's immediate offset, so stepping through a segment costs NO address arithmetic at all: the
+// per-lane pointers stay fixed for the whole segment (rows that read zero padding point at the zero page,
+// where any offset still reads zeros).
+template <int C>
+__device__ __forceinline__ void dma_piece(const DmaSrc& L, int q, float* a_dst, float* b_dst) {
+  if (q < 4)
+    __builtin_amdgcn_global_load_lds((gptr_t)L.aptr[q], (lptr_t)(a_dst + q * 256 - C * GEMM_BK), 16, C * GEMM_BK * 4, 0);
+  else
+    __builtin_amdgcn_global_load_lds((gptr_t)L.bptr[q - 4], (lptr_t)(b_dst + (q - 4) * 256 - C * GEMM_BK), 16,
+                                     C * GEMM_BK * 4, 0);
+}
+template <int C>
+__device__ __forceinline__ void dma_issue(const DmaSrc& L, float* a_dst, float* b_dst) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dma_piece<C>(L, q, a_dst, b_dst);
+}
+
+// CPS = chunks per K-segment (every segment of a launch has the same width), TAIL = the segment's channel
+// count is not a multiple of 32 (its last chunk selects per lane against the K tail).
+template <bool ZOUT, bool RES, int CPS, bool TAIL>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * DTILE_F];  // A0 A1 B0 B1
-  float* const As = lds;
-  float* const Bs = lds + 2 * DTILE_F;
+  __shared__ __attribute__((aligned(16))) float lds[DMA_PAD_F + 4 * DTILE_F + DMA_MAX_N];  // pad A0 A1 B0 B1 shift
+  float* const As = lds + DMA_PAD_F;
+  float* const Bs = As + 2 * DTILE_F;
+  float* const shl = Bs + 2 * DTILE_F;  // per-column shift (folded BN offset / LSTM bias), zero past N
 
   const int tid = threadIdx.x;
+  // The tiles are only ever written by the DMA engine, which the optimiser does not see as a store to `lds`;
+  // one (never taken) ordinary store keeps it from reasoning about a never-written array.
+  if (p.K < 0) lds[tid] = 0.f;
+  for (int n = tid; n < DMA_MAX_N; n += 256) shl[n] = n < p.N ? p.shift[n] : 0.f;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -337,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   const int nblocks_n = (p.N + GEMM_BN - 1) / GEMM_BN;
   const int mblocks = (p.M + GEMM_BM - 1) / GEMM_BM;
   const int total_ids = ((mblocks + 7) / 8) * 8 * nblocks_n;
-  const int nk = p.K / GEMM_BK;
+  const int nseg = p.nseg;
 
   auto tile_of = [&](int id, int& m0, int& n0) -> bool {
     const int xcd = id & 7;
@@ -346,6 +483,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     m0 = mblk * GEMM_BM;
     n0 = (slot % nblocks_n) * GEMM_BN;
     return mblk < mblocks;
+  };
+  auto next_valid = [&](int id) -> int {  // next tile id of this workgroup after `id`, or total_ids
+    int m0, n0;
+    do id += gridDim.x;
+    while (id < total_ids && !tile_of(id, m0, n0));
+    return id;
   };
 
   // ---- DMA geometry: piece j (0..3) of wave w covers tile rows w*32 + j*8 .. +7; lane -> (row, slot)
@@ -358,138 +501,225 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
 #pragma unroll
   for (int g = 0; g < 4; ++g) fslot[g] = ((2 * g + kh) ^ ((li >> 1) & 7)) * 4;
 
-  // ---- loader state machine
-  int l_id = (int)blockIdx.x - (int)gridDim.x;
-  int l_kc = nk;
-  bool l_done = false;
+  // ---- loader: always exactly one chunk ahead of the MFMA loop
+  DmaSrc L;
   int rb[4], rt[4];
   bool rvalid[4];
-  int seg = -1, seg_left = 0, kk = 0, cin = 0;
-  const float* aptr[4];
-  bool aok[4];
-  const float* bptr[4];
-
-  auto next_tile = [&]() {
-    int m0 = 0, n0 = 0;
-    do {
-      l_id += gridDim.x;
-      if (l_id >= total_ids) {
-        l_done = true;
-        return;
-      }
-    } while (!tile_of(l_id, m0, n0));
-    l_kc = 0;
-    seg = -1;
-    seg_left = 0;
+  const float* brow[4];
+  auto load_tile = [&](int id) {
+    int m0, n0;
+    tile_of(id, m0, n0);
+    const RowSplit rs(m0, ZOUT ? p.BP : p.T_out);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      bptr[j] = p.Wt + (long)(n0 + drow + 8 * j) * p.K + dslot[j];
+      brow[j] = p.Wt + (long)(n0 + drow + 8 * j) * p.K + dslot[j];
       const int m = m0 + drow + 8 * j;
       bool v = m < p.M;
       int b, t;
       if (ZOUT) {
-        t = m / p.BP;
-        b = m - t * p.BP;
+        rs.split(drow + 8 * j, t, b);
         v = v && (b < p.B);
       } else {
-        b = m / p.T_out;
-        t = m - b * p.T_out;
+        rs.split(drow + 8 * j, b, t);
       }
       rb[j] = b;
       rt[j] = t;
       rvalid[j] = v;
     }
   };
-
-  auto next_segment = [&]() {
-    ++seg;
-    const GemmSeg& sg = p.seg[seg];
-    seg_left = sg.kpad / GEMM_BK;
-    kk = 0;
-    cin = sg.cin;
+  auto load_segment = [&](const GemmSeg& sg, int k0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int in_t = rt[j] * sg.stride + sg.shift;
       const bool ok = rvalid[j] && in_t >= 0 && in_t < sg.w_in;
-      aok[j] = ok;
       const long row = sg.time_major ? ((long)in_t * p.BP + rb[j]) : ((long)rb[j] * sg.w_in + in_t);
-      aptr[j] = sg.src + (ok ? row * sg.lda : 0) + sg.col0 + dslot[j];
+      L.aok[j] = ok;
+      L.aptr[j] = ok ? sg.src + row * sg.lda + sg.col0 + dslot[j] : p.zero_page + (lane & 7) * 4;
+      L.bptr[j] = brow[j] + k0;
     }
   };
-
-  // issue the DMA of the next chunk into LDS buffer `buf`; false when nothing is left
-  auto dma_chunk = [&](int buf) -> bool {
-    if (l_kc == nk) next_tile();
-    if (l_done) return false;
-    if (seg_left == 0) next_segment();
-    float* a_dst = As + buf * DTILE_F + wave * 1024;   // wave-uniform bases; lanes land at +16 B each
-    float* b_dst = Bs + buf * DTILE_F + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool ok = aok[j] && (kk + dslot[j] < cin);
-      const float* src = ok ? aptr[j] + kk : p.zero_page + (lane & 7) * 4;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 256), 16, 0, 0);
+  // chunk c of a segment whose channel count is not a multiple of 32: per-lane select against the K tail
+  auto tail_piece = [&](int c, int cin, int q, float* a_dst, float* b_dst) {
+    if (q < 4) {
+      const bool ok = L.aok[q] && (c * GEMM_BK + dslot[q] < cin);
+      const float* src = ok ? L.aptr[q] + c * GEMM_BK : p.zero_page + (lane & 7) * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + q * 256), 16, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((gptr_t)(L.bptr[q - 4] + c * GEMM_BK), (lptr_t)(b_dst + (q - 4) * 256), 16, 0, 0);
     }
+  };
+  auto dma_issue_tail = [&](int c, int cin, float* a_dst, float* b_dst) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)bptr[j], (lptr_t)(b_dst + j * 256), 16, 0, 0);
-      bptr[j] += GEMM_BK;
-    }
-    kk += GEMM_BK;
-    --seg_left;
-    ++l_kc;
-    return true;
+    for (int q = 0; q < 8; ++q) tail_piece(c, cin, q, a_dst, b_dst);
   };
 
-  bool more = dma_chunk(0);
-  if (!more) return;
+  int c_id = blockIdx.x;
+  {
+    int m0, n0;
+    if (c_id >= total_ids) return;
+    if (!tile_of(c_id, m0, n0)) c_id = next_valid(c_id);
+    if (c_id >= total_ids) return;
+  }
+  load_tile(c_id);
+  load_segment(p.seg[0], 0);
+  if (TAIL && CPS == 1)
+    dma_issue_tail(0, p.seg[0].cin, As + wave * 1024, Bs + wave * 1024);
+  else
+    dma_issue<0>(L, As + wave * 1024, Bs + wave * 1024);
   int buf = 0;
-  f32x16 acc[2][2];
   bool have_prev = false;
   int pm0 = 0, pn0 = 0;
-
-  for (int c_id = blockIdx.x; c_id < total_ids; c_id += gridDim.x) {
-    int m0, n0;
-    if (!tile_of(c_id, m0, n0)) continue;
-    for (int kc = 0; kc < nk; ++kc) {
-      __syncthreads();  // chunk in `buf` has landed (vmcnt drained before the barrier); buf^1 is free
-      if (more) more = dma_chunk(buf ^ 1);
-      if (kc == 0) {
-        // The previous tile's epilogue is issued HERE, after this tile's first barrier: the barrier's
-        // vmcnt(0) then only ever waits for DMA issued a whole chunk earlier, never for fresh stores.
-        if (have_prev) gemm_epilogue<ZOUT, RES>(p, acc, pm0, pn0, wm, wn, li, kh);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-      }
-      const float* a0 = As + buf * DTILE_F + (wm * 64 + li) * GEMM_BK;
-      const float* b0 = Bs + buf * DTILE_F + (wn * 64 + li) * GEMM_BK;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 a[2], b[2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[g]);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[g]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][j], a[mi][j], acc[mi][ni], 0, 0, 0);
-      }
-      buf ^= 1;
+  f32x16 acc[2][2];
+  const bool relu = p.relu != 0;
+  auto epilogue = [&](int em0, int en0) {
+    if (en0 + GEMM_BN <= p.N && (!ZOUT || 2 * p.z_cols >= p.N)) {
+      if (relu)
+        gemm_epilogue_lean<ZOUT, RES, true>(p, acc, em0, en0, wm, wn, li, kh);
+      else
+        gemm_epilogue_lean<ZOUT, RES, false>(p, acc, em0, en0, wm, wn, li, kh);
+    } else {
+      gemm_epilogue<ZOUT, RES, 0, 16, false>(p, acc, em0, en0, wm, wn, li, kh);
     }
+  };
+
+  // Every non-MFMA instruction in this loop is paid in matrix-pipe time (tools/ubench/mfma_vmem.hip: ~11 pipe
+  // cycles per VALU instruction with two waves per SIMD), so the per-tile bookkeeping is kept off the VALU:
+  // the accumulators are never zeroed and the shift is never added -- the first MFMA of a tile takes its C
+  // operand from a register vector holding the shift (read from LDS), D = acc.
+  while (c_id < total_ids) {
+    int m0, n0;
+    tile_of(c_id, m0, n0);
+    const int n_id = next_valid(c_id);
+    int k0 = 0;
+
+    auto segment = [&](auto first_tag, int sgi) {
+      constexpr bool FS = decltype(first_tag)::value;  // first K-segment of the tile
+      k0 += CPS * GEMM_BK;
+      const bool last_seg = sgi + 1 == nseg;
+
+      // one K-chunk: barrier, start the DMA of the chunk after it, run this one on the matrix pipe
+      auto chunk = [&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        __syncthreads();  // chunk in `buf` has landed (vmcnt drained before the barrier); buf^1 is free
+        float* a_dst = As + (buf ^ 1) * DTILE_F + wave * 1024;  // wave-uniform bases; lanes land at +16 B each
+        float* b_dst = Bs + (buf ^ 1) * DTILE_F + wave * 1024;
+        // The 8 DMA instructions of the next chunk are interleaved with the first 32 MFMAs below instead of
+        // being issued in a burst (all eight waves of the CU share one texture-address unit).
+        bool go = true;
+        if (C + 1 == CPS) {  // first chunk of the next segment / of the next tile: new per-lane pointers
+          int nsg = sgi + 1, nk0 = k0;
+          if (last_seg) {
+            nsg = 0;
+            nk0 = 0;
+            go = n_id < total_ids;
+            if (go) load_tile(n_id);
+          }
+          if (go) load_segment(p.seg[nsg], nk0);
+        }
+        auto piece = [&](int q) {
+          if (!go) return;
+          if (C + 1 < CPS) {
+            if (TAIL && C + 2 == CPS)
+              tail_piece(C + 1, p.seg[sgi].cin, q, a_dst, b_dst);
+            else
+              dma_piece<(C + 1 < CPS ? C + 1 : 0)>(L, q, a_dst, b_dst);
+          } else {
+            if (TAIL && CPS == 1)
+              tail_piece(0, p.seg[0].cin, q, a_dst, b_dst);
+            else
+              dma_piece<0>(L, q, a_dst, b_dst);
+          }
+        };
+        f32x16 ini[2];
+        if (FS && C == 0) {
+          // C operand of the tile's first MFMAs: this lane's 16 shift values per 32-column half
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if (ZOUT) {
+              const float sh = shl[n0 + wn * 64 + ni * 32 + li];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) ini[ni][r] = sh;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shl + n0 + wn * 64 + ni * 32 + 8 * q + 4 * kh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ini[ni][4 * q + r] = sh[r];
+              }
+            }
+          }
+          // The previous tile's epilogue is issued HERE, after this tile's first barrier: the barrier's
+          // vmcnt(0) then only ever waits for DMA issued a whole chunk earlier, never for fresh stores.
+          if (have_prev) epilogue(pm0, pn0);
+        }
+        const float* a0 = As + buf * DTILE_F + (wm * 64 + li) * GEMM_BK;
+        const float* b0 = Bs + buf * DTILE_F + (wn * 64 + li) * GEMM_BK;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 a[2], b[2];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[g]);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[g]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (g < 2) piece(g * 4 + j);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni) {
+                const f32x16 c = (FS && C == 0 && g == 0 && j == 0) ? ini[ni] : acc[mi][ni];
+                acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], c, 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][j], a[mi][j], c, 0, 0, 0);
+              }
+          }
+        }
+        buf ^= 1;
+      };
+      chunk(std::integral_constant<int, 0>{});
+      if (CPS > 1) chunk(std::integral_constant<int, 1>{});
+      if (CPS > 2) chunk(std::integral_constant<int, 2>{});
+      if (CPS > 3) chunk(std::integral_constant<int, 3>{});
+      if (CPS > 4) chunk(std::integral_constant<int, 4>{});
+      if (CPS > 5) chunk(std::integral_constant<int, 5>{});
+      if (CPS > 6) chunk(std::integral_constant<int, 6>{});
+      if (CPS > 7) chunk(std::integral_constant<int, 7>{});
+    };
+    segment(std::true_type{}, 0);
+    for (int sgi = 1; sgi < nseg; ++sgi) segment(std::false_type{}, sgi);
+
     have_prev = true;
     pm0 = m0;
     pn0 = n0;
+    c_id = n_id;
   }
-  if (have_prev) gemm_epilogue<ZOUT, RES>(p, acc, pm0, pn0, wm, wn, li, kh);
+  if (have_prev) epilogue(pm0, pn0);
+}
+
+// The unrolled DMA loop is instantiated for the K-segment widths of the shipped topologies (256 channels;
+// LSTM inputs of 200 = 2H and 100 = H); anything else takes the register-staged kernel.
+template <bool ZOUT, bool RES>
+static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t stream) {
+  const int kpad = p.seg[0].kpad, cin = p.seg[0].cin;
+  if (((p.N + GEMM_BN - 1) / GEMM_BN) * GEMM_BN > DMA_MAX_N) return false;
+  for (int s = 1; s < p.nseg; ++s)
+    if (p.seg[s].kpad != kpad || p.seg[s].cin != cin) return false;
+  const bool tail = cin != kpad;
+  if (kpad == 256 && !tail) {
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<ZOUT, RES, 8, false>), grid, block, 0, stream, p);
+    return true;
+  }
+  if constexpr (ZOUT) {
+    if (kpad == 224 && tail) {
+      hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 7, true>), grid, block, 0, stream, p);
+      return true;
+    }
+    if (kpad == 128 && tail) {
+      hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4, true>), grid, block, 0, stream, p);
+      return true;
+    }
+  }
+  return false;
 }
 
 void launch_gemm(const GemmParams& p, hipStream_t stream) {
@@ -503,19 +733,22 @@ void launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  int g = 2 * n_cu;            // two resident workgroups per CU (73.7 KB LDS, <=168 VGPRs each)
+  int g = 2 * n_cu;            // two resident workgroups per CU (65 KB LDS each)
   g = (g / 8) * 8;
   if (g > total_ids) g = total_ids;
   const dim3 grid(g), block(256);
-  const bool lift = p.seg[0].src == nullptr;
-  if (lift)
+  if (p.seg[0].src == nullptr) {  // lifted signal: A is computed in the loader
     hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, block, 0, stream, p);
-  else if (p.out_mode == 1)
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false>), grid, block, 0, stream, p);
-  else if (p.res_a != nullptr)
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<false, true>), grid, block, 0, stream, p);
-  else
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false>), grid, block, 0, stream, p);
+  } else if (p.out_mode == 1) {
+    if (!launch_dma<true, false>(p, grid, block, stream))
+      hipLaunchKernelGGL((gemm_f32_kernel<false, true, false>), grid, block, 0, stream, p);
+  } else if (p.res_a != nullptr) {
+    if (!launch_dma<false, true>(p, grid, block, stream))
+      hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, block, 0, stream, p);
+  } else {
+    if (!launch_dma<false, false>(p, grid, block, stream))
+      hipLaunchKernelGGL((gemm_f32_kernel<false, false, false>), grid, block, 0, stream, p);
+  }
 }
 
 }  // namespace chiron

@@ -23,6 +23,14 @@ def golden():
 @pytest.fixture(scope="session")
 def built():
     """Build the HIP library + C oracle once per session (hipcc cross-compiles on CPU boxes)."""
+    # Some GPU tests hand torch device tensors to the engine: torch's bundled ROCm runtime has to be the first
+    # one initialised in the process (see chiron_amd/_lib.py), so import it before the library is loaded.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import __graft_entry__ as g
     g.build()
     return True

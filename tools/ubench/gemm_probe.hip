@@ -1,0 +1,75 @@
+// Times the conv-shaped launches of gemm.hip in isolation (conv2a: K = 256, conv2b: 3 taps, K = 768,
+// M = 1100*400, N = 256).  The kernel source is textually included so that experimental variants can be
+// compiled with -DGEMM_SRC=\"...\":
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I chiron_amd/csrc -DGEMM_SRC='"../../chiron_amd/csrc/gemm.hip"' \
+//         tools/ubench/gemm_probe.hip -o tools/ubench/build/gemm_probe
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#ifndef GEMM_SRC
+#define GEMM_SRC "../../chiron_amd/csrc/gemm.hip"
+#endif
+#include GEMM_SRC
+
+using namespace chiron;
+
+int main(int argc, char** argv) {
+  const int B = 1100, T = 400, C = 256;
+  const long M = (long)B * T;
+  float *act, *out, *wt, *shift, *zero;
+  hipMalloc(&act, M * C * 4);
+  hipMalloc(&out, M * C * 4);
+  hipMalloc(&wt, 768 * 256 * 4);
+  hipMalloc(&shift, 256 * 4);
+  hipMalloc(&zero, 4096);
+  hipMemset(zero, 0, 4096);
+  std::vector<float> h(M * C);
+  unsigned s = 12345;
+  for (auto& v : h) {
+    s = s * 1664525u + 1013904223u;
+    v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
+  }
+  hipMemcpy(act, h.data(), M * C * 4, hipMemcpyHostToDevice);
+  hipMemcpy(wt, h.data(), 768 * 256 * 4, hipMemcpyHostToDevice);
+  hipMemcpy(shift, h.data(), 256 * 4, hipMemcpyHostToDevice);
+
+  for (int ntap = 1; ntap <= 3; ntap += 2) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.B = B;
+    g.BP = 1104;
+    g.N = C;
+    g.K = ntap * C;
+    g.Wt = wt;
+    g.shift = shift;
+    g.z_dirs_total = 2;
+    g.zero_page = zero;
+    g.M = (int)M;
+    g.T_out = T;
+    g.nseg = ntap;
+    for (int j = 0; j < ntap; ++j) g.seg[j] = GemmSeg{act, C, 0, C, C, T, 1, j - ntap / 2, 0};
+    g.relu = 1;
+    g.out = out;
+    g.ldo = C;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch_gemm(g, 0);
+    hipDeviceSynchronize();
+    const int reps = 20;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) launch_gemm(g, 0);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    double sum = 0;
+    hipMemcpy(h.data(), out, 1 << 20, hipMemcpyDeviceToHost);
+    for (int i = 0; i < (1 << 18); ++i) sum += h[i];
+    printf("%s K=%d: %.4f ms  %.1f TFLOP/s  (checksum %.6e)\n", argc > 1 ? argv[1] : "", g.K, ms, 2.0 * M * C * g.K / ms * 1e-9, sum);
+  }
+  return 0;
+}
