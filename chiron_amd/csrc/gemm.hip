@@ -24,6 +24,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDS_LD = GEMM_BK + 4;  // 36 floats: 16B-aligned rows, conflict-free b128 access
 constexpr int TILE_F = GEMM_BM * LDS_LD;
 
+// One 4-row group of the x-projection goes to z[t][group][dir][col][4 rows].  The backward direction is stored
+// by STEP instead of by frame: row r lands at s = seq_len[r] - 1 - t (frames past its length are never consumed),
+// so that lstm.hip reads one 16-byte vector per step for either direction, whatever the lengths are.
+struct ZGroup {
+  unsigned base;   // float index of (t = 0, group, dir 0, col 0)
+  unsigned per_t;  // floats per step
+  int t, l0, l1, l2, l3;
+  __device__ __forceinline__ ZGroup(const GemmParams& p, int t_, int b) : t(t_) {
+    per_t = (unsigned)(p.BP >> 2) * p.z_dirs_total * p.z_cols * 4;
+    base = (unsigned)(b >> 2) * p.z_dirs_total * p.z_cols * 4;
+    const int4 len = *reinterpret_cast<const int4*>(p.z_seq_len + b);
+    l0 = min(len.x, p.T_out), l1 = min(len.y, p.T_out), l2 = min(len.z, p.T_out), l3 = min(len.w, p.T_out);
+  }
+  __device__ __forceinline__ void store(const GemmParams& p, int dir, int nl, f32x4 v) const {
+    float* o = p.out + (base + ((unsigned)dir * p.z_cols + nl) * 4);
+    if (dir == 0) {
+      *reinterpret_cast<f32x4*>(o + (unsigned)t * per_t) = v;
+    } else if (l0 == l1 && l1 == l2 && l2 == l3) {
+      if (t < l0) *reinterpret_cast<f32x4*>(o + (unsigned)(l0 - 1 - t) * per_t) = v;
+    } else {
+      if (t < l0) o[(unsigned)(l0 - 1 - t) * per_t + 0] = v[0];
+      if (t < l1) o[(unsigned)(l1 - 1 - t) * per_t + 1] = v[1];
+      if (t < l2) o[(unsigned)(l2 - 1 - t) * per_t + 2] = v[2];
+      if (t < l3) o[(unsigned)(l3 - 1 - t) * per_t + 3] = v[3];
+    }
+  }
+};
+
 // (b, t) of the rows of one 128-row tile without a per-row integer division: the quotient of the tile's first
 // row is wave-uniform, every other row is at most two wrap-arounds away (inner >= 64).
 struct RowSplit {
@@ -87,7 +115,6 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
     }
   } else {
     const RowSplit rs(m0, p.BP);
-    const int nb4 = p.BP >> 2;
     const int zcols = p.z_cols;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -97,7 +124,7 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
         if (m0 + dm >= p.M) continue;
         int t, b;
         rs.split(dm, t, b);
-        float* og = p.out + (((long)t * nb4 + (b >> 2)) * p.z_dirs_total) * zcols * 4;
+        const ZGroup zg(p, t, b);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const int n = n0 + wn * 64 + ni * 32 + li;
@@ -106,7 +133,7 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r];
-          *reinterpret_cast<f32x4*>(og + ((long)dir * zcols + nl) * 4) = v;
+          zg.store(p, dir, nl, v);
         }
       }
     }
@@ -171,7 +198,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       const int n = n0 + wn * 64 + ni * 32 + li;
       if (n >= p.N) continue;
       const float sh = ADD_SHIFT ? p.shift[n] : 0.f;
-      const int nb4 = p.BP >> 2;
       const int zcols = p.z_cols;
       const int dir = p.z_dir0 + n / zcols;
       const int nl = n % zcols;
@@ -187,7 +213,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = ADD_SHIFT ? acc[mi][ni][4 * q + r] + sh : acc[mi][ni][4 * q + r];
-          *reinterpret_cast<f32x4*>(p.out + ((((long)t * nb4 + (b >> 2)) * p.z_dirs_total + dir) * zcols + nl) * 4) = v;
+          ZGroup(p, t, b).store(p, dir, nl, v);
         }
       }
     }
@@ -571,6 +597,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   int pm0 = 0, pn0 = 0;
   f32x16 acc[2][2];
   const bool relu = p.relu != 0;
+  const int tail_groups = TAIL ? (p.seg[0].cin - (CPS - 1) * GEMM_BK + 7) / 8 : 4;  // 8-column groups of the last chunk
   auto epilogue = [&](int em0, int en0) {
     if (en0 + GEMM_BN <= p.N && (!ZOUT || 2 * p.z_cols >= p.N)) {
       if (relu)
@@ -656,6 +683,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
         const float* b0 = Bs + buf * DTILE_F + (wn * 64 + li) * GEMM_BK;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          // K tail: the last chunk of a segment holds only tail_groups * 8 real columns, the rest multiplies zeros
+          if (TAIL && C + 1 == CPS && g >= 2 && g >= tail_groups) continue;
           f32x4 a[2], b[2];
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[g]);

@@ -64,6 +64,8 @@ struct GemmParams {
   int z_ndir;      // out_mode 1: directions interleaved in N (N = z_ndir * z_cols)
   int z_dir0;      // out_mode 1: first direction index written by this launch
   int z_dirs_total;  // out_mode 1: directions in the z buffer (2)
+  const int32_t* z_seq_len;  // out_mode 1: [BP] sequence lengths; direction 1 is stored time-reversed per row:
+                             //   z[s][b][dir 1] = x-projection of frame seq_len[b]-1-s (tf.reverse_sequence folded in)
   const float* zero_page;  // >= 256 B of zeros: DMA source of padded rows / K tails
 };
 
@@ -77,7 +79,8 @@ constexpr int LSTM_NW = 7;       // waves per workgroup; wave w owns hidden unit
 constexpr int LSTM_ZCOLS = 64 * LSTM_NW;  // z columns per direction: wave*64 + gate*16 + (unit & 15)
 
 struct LstmParams {
-  const float* z;        // [T][BP/4][ndir][LSTM_ZCOLS][4 rows]  x-projection + bias, MFMA fragment order
+  const float* z;        // [T][BP/4][ndir][LSTM_ZCOLS][4 rows]  x-projection + bias, MFMA fragment order; direction 1 is
+                         //   indexed by STEP (frame seq_len-1-s), direction 0 by frame
   const float* wfrag;    // [ndir][LSTM_NW][LSTM_K][64 lanes] recurrent weights, fragment order
   const int32_t* seq_len;  // [BP] (0 for padded rows)
   float* out;            // lasth [T][BP][ndir*H] time major

@@ -16,9 +16,10 @@
 //                            + z_t (x-projection, produced by gemm.hip in exactly this fragment order)
 //                            4x4 transpose through LDS: lane (row, unit) gets i, j, f, o of its cell
 //                            c = sig(f)*c + sig(i)*tanh(j);  h = sig(o)*tanh(c)   (forget bias folded in z)
-//   h is exchanged through a double-buffered [4 rows][100] LDS tile per group, one barrier per step.
+//   h is exchanged through a double-buffered 2 KB LDS tile per group (A-operand order, see HG), one barrier per step.
 //   Masking: rows with t >= seq_len emit 0 and carry (c,h); the backward direction walks
-//   t = seq_len-1-s per row (tf.reverse_sequence folded into index arithmetic, no copy).
+//   t = seq_len-1-s per row (tf.reverse_sequence folded into index arithmetic, no copy): its z is stored by step
+//   by the projection GEMM, its output frame index is per-lane arithmetic.
 #include "kernels.h"
 
 // Every multiply-add below is written out (fmaf or separate ops) so that a row's result does not depend on
@@ -29,7 +30,11 @@ namespace chiron {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int HS4 = 104;  // LDS row stride (floats) of an h row: 16-byte aligned rows for ds_read_b128
+// h_{t-1} of one 4-row group in LDS, in the order the MFMA A operand wants it: lane (blk = lane>>2, row = lane&3)
+// keeps h[row][16q + blk], q = 0..7, in 8 consecutive floats (two ds_read_b128 per step).  The 4x4x1 MFMA for
+// k = 16q + blk then BROADCASTS block blk's A vector to all 16 blocks (cbsz = 4, abid = blk; semantics checked in
+// tools/ubench/mfma4x4_bcast.hip), so a wave reads 2 KB of h per step instead of 25.6 KB.
+constexpr int HG = 16 * 4 * 8;  // floats per group and buffer
 
 __device__ __forceinline__ float fast_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
@@ -39,97 +44,9 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f), 1.0f);
 }
 
-template <int NG, bool UNIFORM>
-__device__ __forceinline__ void lstm_loop(const LstmParams& p, const float (&w)[LSTM_K], float* hbuf, float* tbuf,
-                                          const int (&len4)[NG][4], const int (&lenr)[NG], int maxlen, int dir, int g0,
-                                          int wave, int lane) {
-  const int unit = wave * 16 + (lane & 15);
-  const int row = lane >> 4;         // after the transpose: this lane's batch row within the group
-  const bool live = unit < p.H;
-  const int nb4 = p.BP >> 2;
-  const int outw = p.ndir * p.H;
-  const long zstep = (long)nb4 * p.ndir * LSTM_ZCOLS * 4;  // floats between consecutive t
-  const float* zb = p.z + (((long)g0 * p.ndir + dir) * LSTM_ZCOLS + wave * 64 + lane) * 4;
-  const long zgrp = (long)p.ndir * LSTM_ZCOLS * 4;         // floats between consecutive row groups
-  float* tw = tbuf + wave * NG * 256;                      // this wave's transpose scratch
-
-  float c[NG], hprev[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) c[g] = hprev[g] = 0.f;
-
-  int cur = 0;
-  for (int s = 0; s < maxlen; ++s) {
-    // ---- z_t for the 4 rows of each group (one 16-byte load per lane when t is uniform)
-    f32x4 z[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (UNIFORM) {
-        const int t = dir == 0 ? s : maxlen - 1 - s;
-        z[g] = *reinterpret_cast<const f32x4*>(zb + t * zstep + g * zgrp);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool a = s < len4[g][r];
-          const int t = dir == 0 ? s : (a ? len4[g][r] - 1 - s : 0);
-          z[g][r] = zb[t * zstep + g * zgrp + r];
-        }
-      }
-    }
-    // ---- acc = h_{s-1} . W_hh : A[block][i] = h[row i][k] for every block, B = this lane's column of W_hh
-    constexpr int NA = NG == 1 ? 2 : 1;  // a lone group alternates two accumulators (dependent MFMA = 12 cycles)
-    f32x4 acc[NG][NA];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int a = 0; a < NA; ++a) acc[g][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* hb = hbuf + cur * (NG * 4 * HS4) + (lane & 3) * HS4;
-#pragma unroll
-    for (int q = 0; q < LSTM_K / 4; ++q) {
-      f32x4 a4[NG];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) a4[g] = *reinterpret_cast<const f32x4*>(hb + g * 4 * HS4 + 4 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          acc[g][(q * 4 + j) % NA] =
-              __builtin_amdgcn_mfma_f32_4x4x1f32(a4[g][j], w[4 * q + j], acc[g][(q * 4 + j) % NA], 0, 0, 0);
-    }
-    // ---- gates: transpose (lane = gate*16+unit, reg = row) -> (lane = row*16+unit, reg = gate)
-    float* hn = hbuf + (cur ^ 1) * (NG * 4 * HS4);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      f32x4 v = acc[g][0];
-      if (NA == 2) v += acc[g][NA - 1];
-      v += z[g];
-      float* ts = tw + g * 256;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ts[(r * 16 + (lane & 15)) * 4 + (lane >> 4)] = v[r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const f32x4 q = *reinterpret_cast<const f32x4*>(tw + g * 256 + lane * 4);  // i, j, f, o of (row, unit)
-      const bool act = UNIFORM ? true : (s < lenr[g]);
-      const float cn = fmaf(fast_sigmoid(q[2]), c[g], fast_sigmoid(q[0]) * fast_tanh(q[1]));
-      const float hnew = fast_sigmoid(q[3]) * fast_tanh(cn);
-      c[g] = act ? cn : c[g];
-      hprev[g] = act ? hnew : hprev[g];
-      if (live) {
-        hn[(g * 4 + row) * HS4 + unit] = hprev[g];
-        const int to = dir == 0 ? s : (UNIFORM ? maxlen - 1 - s : (act ? lenr[g] - 1 - s : s));
-        p.out[((long)to * p.BP + (g0 + g) * 4 + row) * outw + dir * p.H + unit] = act ? hnew : 0.f;
-      }
-    }
-    cur ^= 1;
-    __syncthreads();
-  }
-}
-
 template <int NG>
 __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(const LstmParams p) {
-  __shared__ __attribute__((aligned(16))) float hbuf[2 * NG * 4 * HS4];
+  __shared__ __attribute__((aligned(16))) float hbuf[2 * NG * HG];
   __shared__ __attribute__((aligned(16))) float tbuf[LSTM_NW * NG * 256];
 
   const int tid = threadIdx.x;
@@ -145,36 +62,123 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
 #pragma unroll
     for (int k = 0; k < LSTM_K; ++k) w[k] = wf[k * 64];
   }
-  for (int i = tid; i < 2 * NG * 4 * HS4; i += 64 * LSTM_NW) hbuf[i] = 0.f;
+  for (int i = tid; i < 2 * NG * HG; i += 64 * LSTM_NW) hbuf[i] = 0.f;
 
-  int len4[NG][4], lenr[NG];
-  int maxlen = 0, minlen = 1 << 30;
+  const int unit = wave * 16 + (lane & 15);
+  const int row = lane >> 4;  // after the transpose: this lane's batch row within the group
+  const bool live = unit < p.H;
+  int lenr[NG];               // length of this lane's row
+  int maxlen = 0;             // longest row of the workgroup (wave-uniform)
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
+    lenr[g] = min(p.seq_len[(g0 + g) * 4 + row], p.T);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      len4[g][r] = min(p.seq_len[(g0 + g) * 4 + r], p.T);
-      maxlen = max(maxlen, len4[g][r]);
-      minlen = min(minlen, len4[g][r]);
-    }
-    lenr[g] = len4[g][0];
-#pragma unroll
-    for (int r = 1; r < 4; ++r) lenr[g] = (lane >> 4) == r ? len4[g][r] : lenr[g];
+    for (int r = 0; r < 4; ++r) maxlen = max(maxlen, min(p.seq_len[(g0 + g) * 4 + r], p.T));
   }
   __syncthreads();
 
-  if (minlen == maxlen)
-    lstm_loop<NG, true>(p, w, hbuf, tbuf, len4, lenr, maxlen, dir, g0, wave, lane);
-  else
-    lstm_loop<NG, false>(p, w, hbuf, tbuf, len4, lenr, maxlen, dir, g0, wave, lane);
+  // all offsets are 32-bit element indices (z: < 2^29 floats at B = 1100, T = 400): scalar base + one VGPR
+  const unsigned outw = p.ndir * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * LSTM_ZCOLS * 4;  // floats between consecutive steps
+  const unsigned zlane = ((g0 * p.ndir + dir) * LSTM_ZCOLS + wave * 64 + lane) * 4;
+  const unsigned zgrp = p.ndir * LSTM_ZCOLS * 4;                 // floats between consecutive row groups
+  const unsigned ostep = p.BP * outw;                            // floats between consecutive frames of the output
+  const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
+  float* tw = tbuf + wave * NG * 256;                            // this wave's transpose scratch
+  const int hw = ((lane & 15) * 4 + row) * 8 + wave;             // where this lane's cell writes h: blk = unit & 15, q = wave
+
+  float c[NG], hprev[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) c[g] = hprev[g] = 0.f;
+
+  // z of step s: ONE 16-byte load per lane and group.  The projection GEMM stores the backward direction by step
+  // (frame seq_len-1-s of each row, gemm.hip ZGroup), so neither direction needs per-row addressing here.
+  // hipcc sinks an ordinary load down to its first use, where every step would pay a full HBM round trip.  So the
+  // load is issued by hand at the TOP of the step and waited for after the MFMAs, and a 4-byte "touch" of the
+  // slab two steps ahead pulls those lines into L2 early.  (Registers are the limit here -- 128 per lane with two
+  // workgroups per CU, 100 of them hold W_hh -- which rules out a double-buffered 16-byte prefetch.)
+  const unsigned zlane_b = zlane * 4;  // byte offset of this lane inside a step's z slab (scalar base + VGPR offset)
+  int cur = 0;
+  for (int s = 0; s < maxlen; ++s) {
+    f32x4 z[NG];
+    float touch;
+    {
+      const float* zs = p.z + (size_t)s * zstep;  // wave-uniform
+      const float* zt = p.z + (size_t)min(s + 2, maxlen - 1) * zstep;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z[g]) : "v"(zlane_b), "s"(zs + g * zgrp) : "memory");
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(touch) : "v"(zlane_b), "s"(zt + g * zgrp) : "memory");
+    }
+    // ---- acc = h_{s-1} . W_hh : A = h[row][k] broadcast from block k&15, B = this lane's column of W_hh.
+    //      One accumulator per group: the 12-cycle dependent-issue latency of the chain is covered by the other
+    //      waves of the SIMD (3-4 are resident), a second accumulator would cost 4 registers that do not exist.
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* hb = hbuf + cur * (NG * HG) + lane * 8;
+    f32x4 hv0[NG];
+    float hv1[NG][3];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      hv0[g] = *reinterpret_cast<const f32x4*>(hb + g * HG);
+      const float2 t2 = *reinterpret_cast<const float2*>(hb + g * HG + 4);
+      hv1[g][0] = t2.x;
+      hv1[g][1] = t2.y;
+      hv1[g][2] = hb[g * HG + 6];
+    }
+#define CHIRON_MF(B)                                                                                       \
+  if (16 * q + (B) < LSTM_K)                                                                                \
+    acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq, w[(16 * q + (B)) % LSTM_K], acc[g], 4, B, 0);
+#pragma unroll
+    for (int q = 0; q < (LSTM_K + 15) / 16; ++q) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float hq = q < 4 ? hv0[g][q & 3] : hv1[g][(q - 4) % 3];
+        CHIRON_MF(0) CHIRON_MF(1) CHIRON_MF(2) CHIRON_MF(3) CHIRON_MF(4) CHIRON_MF(5) CHIRON_MF(6) CHIRON_MF(7)
+        CHIRON_MF(8) CHIRON_MF(9) CHIRON_MF(10) CHIRON_MF(11) CHIRON_MF(12) CHIRON_MF(13) CHIRON_MF(14) CHIRON_MF(15)
+      }
+    }
+#undef CHIRON_MF
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[0]), "+v"(touch));
+    // ---- gates: transpose (lane = gate*16+unit, reg = row) -> (lane = row*16+unit, reg = gate)
+    float* hn = hbuf + (cur ^ 1) * (NG * HG);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 v = acc[g] + z[g];
+      float* ts = tw + g * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ts[(r * 16 + (lane & 15)) * 4 + (lane >> 4)] = v[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(tw + g * 256 + lane * 4);  // i, j, f, o of (row, unit)
+      // rows past their length carry (c, h) and emit zeros (dynamic_rnn); whatever their z slot held is discarded
+      const bool act = s < lenr[g];
+      const float cn = fmaf(fast_sigmoid(q[2]), c[g], fast_sigmoid(q[0]) * fast_tanh(q[1]));
+      const float hnew = fast_sigmoid(q[3]) * fast_tanh(cn);
+      c[g] = act ? cn : c[g];
+      hprev[g] = act ? hnew : hprev[g];
+      if (live) {
+        hn[g * HG + hw] = hprev[g];
+        const unsigned to = (dir == 0 || !act) ? s : lenr[g] - 1 - s;  // the backward direction walks its frames from the end
+        p.out[to * ostep + g * 4 * outw + olane] = act ? hnew : 0.f;
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
 
   // ---- frames past the longest row of this workgroup read back as zeros (dynamic_rnn semantics)
-  const int outw = p.ndir * p.H;
   for (int s = maxlen; s < p.T; ++s) {
     for (int i = tid; i < NG * 4 * p.H; i += 64 * LSTM_NW) {
-      const int row = i / p.H;
-      const int unit = i - row * p.H;
-      p.out[((long)s * p.BP + g0 * 4 + row) * outw + dir * p.H + unit] = 0.f;
+      const int r = i / p.H;
+      const int u = i - r * p.H;
+      p.out[((long)s * p.BP + g0 * 4 + r) * outw + dir * p.H + u] = 0.f;
     }
   }
 }
