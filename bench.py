@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--slots", type=int, default=3, help="batches in flight (engine slots / HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-f16", action="store_true", help="skip the extra BASELINE configs[4] (fp16, batch 4096) measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -207,12 +208,51 @@ def main():
                       "lstm_gemm_roofline_frac_whole_path": round(windows / dt * LSTM_GEMM_FLOP_PER_WINDOW / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                       "model_tflops_whole_path": round(windows / dt * MODEL_FLOP_PER_WINDOW / 1e12, 2),
                       "gemm_family": gemm_family, "kernels": per_kernel}}
+    ref32 = None
+    if rank == 0 and world == 1 and not args.no_f16:
+        ref32 = eng.infer(x_dev[0], s_dev[0], want_logits=True)
     eng.close()
+    if ref32 is not None:
+        out["extra"]["config5_f16"] = f16_config(spec, weights, x_dev, s_dev, ref32, local_rank)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def f16_config(spec, weights, x_dev, s_dev, ref32, device_id):
+    """BASELINE.json configs[4] (a parity-test case, reported next to the headline, never as `value`): fp16 conv +
+    LSTM on the f16 MFMA instructions with fp32 accumulation / gates / CTC, batch 4096, same synthetic workload;
+    plus the tolerance check of its logits against the fp32 engine on the first 1100 windows."""
+    import torch
+    import chiron_amd as ca
+    B16, steps = 4096, 6
+    reps = -(-B16 // BATCH)
+    x = torch.cat([x_dev[i % len(x_dev)] for i in range(reps)])[:B16].contiguous()
+    sl = torch.cat([s_dev[i % len(s_dev)] for i in range(reps)])[:B16].contiguous()
+    with ca.Engine(spec, weights, max_batch=B16, segment_len=SEG_LEN, device_id=device_id, n_slots=2, dtype="fp16") as e16:
+        r16 = e16.infer(x_dev[0], s_dev[0], want_logits=True)
+        T = r16.logits.shape[1]
+        mask = np.arange(T)[None, :] < s_dev[0].cpu().numpy()[:, None]
+        d = np.abs(r16.logits - ref32.logits)[mask]
+        for i in range(2):
+            e16.submit(i, x, sl, beam_width=0, want_prob=True)
+        for i in range(2):
+            e16.collect(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if i >= 2:
+                e16.collect(i % 2)
+            e16.submit(i % 2, x, sl, beam_width=0, want_prob=True)
+        for i in range(2):
+            e16.collect(i)
+        e16.sync()
+        dt = time.perf_counter() - t0
+    return {"workload": "DNA_default seg_len=400 jump=390 batch=4096 greedy, fp16 conv+LSTM / fp32 accumulate, gates, CTC",
+            "kbases_per_s": round(steps * B16 * BASES_PER_WINDOW / 1000.0 / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3),
+            "logits_vs_f32": {"max_abs": round(float(d.max()), 5), "mean_abs": round(float(d.mean()), 6), "windows": BATCH}}
 
 
 def pmc_traffic(kernel):

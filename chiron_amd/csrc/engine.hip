@@ -185,6 +185,8 @@ struct chiron_engine {
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
   int lstm_rows = 4;   // batch rows per recurrence workgroup (4, 8 or 16)
+  bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
+  int kq = GEMM_BK;    // K padding quantum in elements: one LDS chunk = 128 bytes per row (32 floats / 64 halves)
   std::vector<BlockPlan> blocks;
   std::vector<LstmPlan> lstm;
   float *fc_w = nullptr, *fc_b = nullptr, *fc_wc = nullptr, *fc_bc = nullptr;
@@ -231,8 +233,16 @@ static chiron_status upload_gemm(chiron_engine* e, ConvGemmPlan* g, const std::v
   g->N = N;
   g->Npad = Npad;
   g->K = K;
-  chiron_status st = dev_upload(e, &g->Wt, Wt);
-  if (st) return st;
+  chiron_status st;
+  if (e->f16) {
+    std::vector<_Float16> h(Wt.size());
+    for (size_t i = 0; i < Wt.size(); ++i) h[i] = (_Float16)Wt[i];
+    _Float16* d = nullptr;
+    if ((st = dev_upload(e, &d, h))) return st;
+    g->Wt = reinterpret_cast<float*>(d);
+  } else if ((st = dev_upload(e, &g->Wt, Wt))) {
+    return st;
+  }
   return dev_upload(e, &g->shift, shift);
 }
 
@@ -241,6 +251,12 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
   if (d.bn_mode != CHIRON_BN_POPULATION)
     return fail(CHIRON_ERR_INVALID, "bn_mode=batch (HEAD simple_global_bn) is not implemented in this build; "
                                     "the shipped checkpoints use population statistics");
+  if (e->f16) {
+    for (int bi = 0; bi < d.n_blocks; ++bi)
+      if (d.blocks[bi].out_channels % GEMM_BN || (d.blocks[bi].in_channels != 1 && d.blocks[bi].in_channels % 64))
+        return fail(CHIRON_ERR_INVALID, "dtype f16: block %d has %d -> %d channels; the f16 kernels need multiples of 64 / 128", bi,
+                    d.blocks[bi].in_channels, d.blocks[bi].out_channels);
+  }
   int t = e->L;
   const float* p = w;
   for (int bi = 0; bi < d.n_blocks; ++bi) {
@@ -278,7 +294,7 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
     p += 4 * co;
 
     const int Npad = roundup(co, GEMM_BN);
-    const int cop = roundup(co, GEMM_BK);
+    const int cop = roundup(co, e->kq);
     chiron_status st;
     // conv2b: Wt[n][tap*cop + c] = W2b[tap][c][n] * inv2b[n]
     {
@@ -310,7 +326,7 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       }
       if ((st = upload_gemm(e, &bp.gc, Wt, sh, co, Npad, K))) return st;
     } else {
-      const int cip = roundup(ci, GEMM_BK);
+      const int cip = roundup(ci, e->kq);
       {
         const int K = cip;
         std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
@@ -355,7 +371,7 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
     }
     const bool split = d.rnn_kind == CHIRON_RNN_MULTI && l > 0;
     lp.nproj = split ? 2 : 1;
-    const int Kp = roundup(lp.in_w, GEMM_BK);
+    const int Kp = roundup(lp.in_w, e->kq);
     chiron_status st;
     for (int pj = 0; pj < lp.nproj; ++pj) {
       const int ndir = split ? 1 : 2;
@@ -384,7 +400,25 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
             if (k < H && unit < H) v = kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + unit];
             wf[(((size_t)dir * LSTM_NW + wv) * LSTM_K + k) * 64 + lane] = v;
           }
-    if ((st = dev_upload(e, &lp.wfrag, wf))) return st;
+    if (e->f16) {
+      // v_mfma_f32_4x4x4_16B_f16 B-operand order: [dir][wave][k-step j][lane][4 halves], k = 4j .. 4j+3
+      std::vector<_Float16> wh((size_t)2 * LSTM_NW * LSTM_KSTEPS16 * 64 * 4, (_Float16)0.f);
+      for (int dir = 0; dir < 2; ++dir)
+        for (int wv = 0; wv < LSTM_NW; ++wv)
+          for (int j = 0; j < LSTM_KSTEPS16; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int q = 0; q < 4; ++q) {
+                const int k = 4 * j + q, g = lane >> 4, unit = 16 * wv + (lane & 15);
+                if (k < H && unit < H)
+                  wh[((((size_t)dir * LSTM_NW + wv) * LSTM_KSTEPS16 + j) * 64 + lane) * 4 + q] =
+                      (_Float16)kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + unit];
+              }
+      _Float16* d16 = nullptr;
+      if ((st = dev_upload(e, &d16, wh))) return st;
+      lp.wfrag = reinterpret_cast<float*>(d16);
+    } else if ((st = dev_upload(e, &lp.wfrag, wf))) {
+      return st;
+    }
     e->lstm.push_back(lp);
   }
   // ---- FC head (raw)
@@ -411,7 +445,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   const size_t B = e->maxB, BP = e->BP, L = e->L, T = e->T, H = e->H, K = e->K;
   size_t tmax = 0, cmax = 0;
   for (const BlockPlan& b : e->blocks) {
-    if (!b.lift) tmax = std::max<size_t>(tmax, b.t_in);
+    if (!b.lift || e->f16) tmax = std::max<size_t>(tmax, b.t_in);  // f16 materialises the lifted conv2a at input resolution
     tmax = std::max<size_t>(tmax, b.t_out);
     cmax = std::max<size_t>(cmax, b.c);
   }
@@ -419,7 +453,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   if ((st = dev_alloc(e, (void**)&s->sig, B * L * 4, true))) return st;
   if ((st = dev_alloc(e, (void**)&s->seq, BP * 4, true))) return st;
   for (int i = 0; i < 3; ++i)
-    if ((st = dev_alloc(e, (void**)&s->act[i], B * tmax * cmax * 4, false))) return st;
+    if ((st = dev_alloc(e, (void**)&s->act[i], B * tmax * cmax * (e->f16 ? 2 : 4), false))) return st;
   if ((st = dev_alloc(e, (void**)&s->z, T * BP * 2 * LSTM_ZCOLS * 4, true))) return st;
   for (int i = 0; i < 2; ++i)
     if ((st = dev_alloc(e, (void**)&s->lasth[i], T * BP * 2 * H * 4, true))) return st;
@@ -459,7 +493,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   chiron_weights_size(desc, &want);
   if (want != n_floats) return fail(CHIRON_ERR_INVALID, "weight blob has %zu floats, descriptor needs %zu", n_floats, want);
   if (opts->max_batch < 1 || opts->segment_len < 1) return fail(CHIRON_ERR_INVALID, "max_batch/segment_len must be positive");
-  if (opts->dtype != CHIRON_F32) return fail(CHIRON_ERR_INVALID, "dtype %d not available in this build (fp32 parity path only)", opts->dtype);
+  if (opts->dtype != CHIRON_F32 && opts->dtype != CHIRON_F16) return fail(CHIRON_ERR_INVALID, "dtype %d unknown (0 = f32, 1 = f16)", opts->dtype);
   if (desc->hidden != 100) return fail(CHIRON_ERR_INVALID, "hidden=%d: the recurrence kernel is built for hidden=100 (both shipped models)", desc->hidden);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CHIRON_ERR_DEVICE, "no HIP device visible: libchiron_amd has no CPU fallback");
@@ -475,6 +509,8 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->K = desc->classes;
   e->maxB = opts->max_batch;
   e->BP = roundup(opts->max_batch, 16);
+  e->f16 = opts->dtype == CHIRON_F16;
+  e->kq = e->f16 ? 2 * GEMM_BK : GEMM_BK;
   {
     const char* ev = getenv("CHIRON_LSTM_ROWS");  // tuning knob; results do not depend on it
     const int r = ev ? atoi(ev) : 4;
@@ -560,11 +596,28 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
   g->zero_page = e->zero_page;
 }
 
-static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
+// Segments are filled in ELEMENTS; the f16 kernels address in 4-byte units (see GemmParams::f16).
+static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
+  if (e->f16) {
+    g.f16 = 1;
+    for (int i = 0; i < g.nseg; ++i) {
+      g.seg[i].lda /= 2;
+      g.seg[i].col0 /= 2;
+      g.seg[i].cin /= 2;
+      g.seg[i].kpad /= 2;
+    }
+    g.K /= 2;
+    if (g.out_mode == 0) g.ldo /= 2;
+  }
+  return launch_gemm(g, stream);
+}
+
+static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
+  bool ok = true;
   float* x = nullptr;  // block input (channels-last [B*T][C])
   int xi = -1;         // which act buffer holds x
   for (const BlockPlan& b : e->blocks) {
-    const int cop = roundup(b.c, GEMM_BK);
+    const int cop = roundup(b.c, e->kq);
     // pick two scratch buffers different from x
     int ia = (xi + 1) % 3, ib = (xi + 2) % 3;
     if (xi < 0) {
@@ -580,17 +633,26 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.M = B * b.t_out;
       g.T_out = b.t_out;
       g.nseg = b.k;
-      for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{nullptr, 0, 0, b.c, cop, b.t_in, b.stride, j - b.left, 0};
       g.relu = 1;
-      g.sig = sig;
-      g.L = e->L;
-      g.lift_a = b.lift_a;
-      g.lift_b = b.lift_b;
       g.out = bufB;
       g.ldo = b.c;
-      {
+      if (e->f16) {
+        // f16: conv2a of the signal is materialised as halves, conv2b is then an ordinary DMA launch
+        {
+          Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_in * b.c, 4.0 * B * b.t_in + 2.0 * B * b.t_in * b.c);
+          launch_lift_f16(sig, b.lift_a, b.lift_b, bufA, (long)B * b.t_in, b.c, s->stream);
+        }
+        for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{bufA, b.c, 0, b.c, cop, b.t_in, b.stride, j - b.left, 0};
+        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 2.0 * B * (b.t_in + b.t_out) * b.c);
+        ok &= launch(e, g, s->stream);
+      } else {
+        for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{nullptr, 0, 0, b.c, cop, b.t_in, b.stride, j - b.left, 0};
+        g.sig = sig;
+        g.L = e->L;
+        g.lift_a = b.lift_a;
+        g.lift_b = b.lift_b;
         Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * b.t_out * b.c);
-        launch_gemm(g, s->stream);
+        ok &= launch(e, g, s->stream);
       }
       // conv2c + lifted branch1 + ReLU
       init_gemm(&g, e, b.gc, B);
@@ -607,12 +669,12 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.ldo = b.c;
       {
         Prof pr(e, s, PN_RES, 2.0 * B * b.t_out * (double)b.c * b.c, 8.0 * B * b.t_out * b.c);
-        launch_gemm(g, s->stream);
+        ok &= launch(e, g, s->stream);
       }
       x = bufA;
       xi = ia;
     } else {
-      const int cip = roundup(b.c_in, GEMM_BK);
+      const int cip = roundup(b.c_in, e->kq);
       // conv2a
       init_gemm(&g, e, b.ga, B);
       g.M = B * b.t_in;
@@ -624,7 +686,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.ldo = b.c;
       {
         Prof pr(e, s, PN_CONV, 2.0 * B * b.t_in * (double)b.c_in * b.c, 4.0 * B * b.t_in * (b.c_in + b.c));
-        launch_gemm(g, s->stream);
+        ok &= launch(e, g, s->stream);
       }
       // conv2b
       init_gemm(&g, e, b.gb, B);
@@ -637,7 +699,7 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.ldo = b.c;
       {
         Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * (b.t_in + b.t_out) * b.c);
-        launch_gemm(g, s->stream);
+        ok &= launch(e, g, s->stream);
       }
       // conv2c + branch1/conv1 fused along K, + ReLU
       init_gemm(&g, e, b.gc, B);
@@ -651,16 +713,18 @@ static void run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.ldo = b.c;
       {
         Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)(b.c + b.c_in) * b.c, 4.0 * B * b.t_out * (2.0 * b.c + b.c_in));
-        launch_gemm(g, s->stream);
+        ok &= launch(e, g, s->stream);
       }
       x = bufA;
       xi = ia;
     }
   }
   s->sig_used = x;  // CNN feature [B*T][C]
+  return ok;
 }
 
-static void run_rnn(chiron_engine* e, Slot* s, int B) {
+static bool run_rnn(chiron_engine* e, Slot* s, int B) {
+  bool ok = true;
   const float* fea = s->sig_used;
   const int T = e->T, H = e->H, BP = e->BP;
   const int zc = LSTM_ZCOLS;
@@ -675,7 +739,7 @@ static void run_rnn(chiron_engine* e, Slot* s, int B) {
       g.T_out = T;
       g.m_time_major = 1;
       g.nseg = 1;
-      const int Kp = roundup(lp.in_w, GEMM_BK);
+      const int Kp = roundup(lp.in_w, e->kq);
       if (l == 0)
         g.seg[0] = GemmSeg{fea, e->C, 0, e->C, Kp, T, 1, 0, 0};
       else if (lp.nproj == 1)
@@ -690,7 +754,7 @@ static void run_rnn(chiron_engine* e, Slot* s, int B) {
       g.z_seq_len = s->seq;
       const double ndir = lp.nproj == 1 ? 2.0 : 1.0;
       Prof pr(e, s, PN_PROJ, 2.0 * B * T * (double)lp.in_w * 4 * H * ndir, 4.0 * B * T * (lp.in_w + ndir * zc));
-      launch_gemm(g, s->stream);
+      ok &= launch(e, g, s->stream);
     }
     LstmParams r;
     r.z = s->z;
@@ -703,6 +767,7 @@ static void run_rnn(chiron_engine* e, Slot* s, int B) {
     r.H = H;
     r.ndir = 2;
     r.rows_per_wg = e->lstm_rows;
+    r.f16 = e->f16 ? 1 : 0;
     {
       Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H, 4.0 * B * T * 2.0 * (zc + H));
       launch_lstm(r, s->stream);
@@ -721,10 +786,12 @@ static void run_rnn(chiron_engine* e, Slot* s, int B) {
   f.BP = BP;
   f.H = H;
   f.K = e->K;
+  f.f16 = e->f16 ? 1 : 0;
   {
     Prof pr(e, s, PN_FC, 2.0 * B * T * (2.0 * H + (double)H * e->K), 4.0 * B * T * (2.0 * H + e->K));
     launch_fc(f, s->stream);
   }
+  return ok;
 }
 
 static chiron_status enqueue_decode(chiron_engine* e, Slot* s, int B, int beam_width, uint32_t flags) {
@@ -801,8 +868,8 @@ extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, co
     HIP_TRY(hipMemcpyAsync(s->seq, s->h_seq, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
     sig = s->sig;
   }
-  run_cnn(e, s, B, sig);
-  run_rnn(e, s, B);
+  if (!run_cnn(e, s, B, sig) || !run_rnn(e, s, B))
+    return fail(CHIRON_ERR_INVALID, "a GEMM of this topology has no kernel for the engine's dtype");
 
   {
     chiron_status st = enqueue_decode(e, s, B, beam_width, flags);

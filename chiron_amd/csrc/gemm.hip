@@ -20,6 +20,8 @@ namespace chiron {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDS_LD = GEMM_BK + 4;  // 36 floats: 16B-aligned rows, conflict-free b128 access
 constexpr int TILE_F = GEMM_BM * LDS_LD;
@@ -77,7 +79,7 @@ struct RowSplit {
 // Epilogue of the DMA kernel for a tile that lies completely inside N: no per-store bounds checks or branches,
 // one base address per row (the stores use immediate offsets), ReLU as one v_med3 per value, shift already in
 // the accumulators.  ~100 VALU instructions per tile instead of ~350 -- they are all paid in matrix-pipe time.
-template <bool ZOUT, bool RES, bool RELU>
+template <bool ZOUT, bool RES, bool RELU, bool F16OUT = false>
 __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
                                                    int li, int kh) {
   if (!ZOUT) {
@@ -92,7 +94,8 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
         rs.split(wm * 64 + mi * 32 + li, b, t);
         sv = p.sig[(long)b * p.L + (long)t * p.res_stride];
       }
-      float* orow = p.out + (long)m * p.ldo + n0 + wn * 64 + 4 * kh;
+      // f16 output: ldo counts 4-byte units, a row holds 2*ldo halves
+      float* orow = p.out + (long)m * p.ldo + (F16OUT ? (n0 + wn * 64 + 4 * kh) / 2 : n0 + wn * 64 + 4 * kh);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -109,7 +112,14 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, INFINITY);
           }
-          *reinterpret_cast<f32x4*>(orow + ni * 32 + 8 * q) = v;
+          if (F16OUT) {
+            f16x4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
+            *reinterpret_cast<f16x4*>(orow + (ni * 32 + 8 * q) / 2) = hv;
+          } else {
+            *reinterpret_cast<f32x4*>(orow + ni * 32 + 8 * q) = v;
+          }
         }
       }
     }
@@ -479,7 +489,7 @@ __device__ __forceinline__ void dma_issue(const DmaSrc& L, float* a_dst, float* 
 
 // CPS = chunks per K-segment (every segment of a launch has the same width), TAIL = the segment's channel
 // count is not a multiple of 32 (its last chunk selects per lane against the K tail).
-template <bool ZOUT, bool RES, int CPS, bool TAIL>
+template <bool ZOUT, bool RES, int CPS, bool TAIL, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[DMA_PAD_F + 4 * DTILE_F + DMA_MAX_N];  // pad A0 A1 B0 B1 shift
   float* const As = lds + DMA_PAD_F;
@@ -599,11 +609,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   const bool relu = p.relu != 0;
   const int tail_groups = TAIL ? (p.seg[0].cin - (CPS - 1) * GEMM_BK + 7) / 8 : 4;  // 8-column groups of the last chunk
   auto epilogue = [&](int em0, int en0) {
-    if (en0 + GEMM_BN <= p.N && (!ZOUT || 2 * p.z_cols >= p.N)) {
+    if ((F16 && !ZOUT) || (en0 + GEMM_BN <= p.N && (!ZOUT || 2 * p.z_cols >= p.N))) {  // f16 conv: N % 128 == 0 (launch_gemm)
       if (relu)
-        gemm_epilogue_lean<ZOUT, RES, true>(p, acc, em0, en0, wm, wn, li, kh);
+        gemm_epilogue_lean<ZOUT, RES, true, F16 && !ZOUT>(p, acc, em0, en0, wm, wn, li, kh);
       else
-        gemm_epilogue_lean<ZOUT, RES, false>(p, acc, em0, en0, wm, wn, li, kh);
+        gemm_epilogue_lean<ZOUT, RES, false, F16 && !ZOUT>(p, acc, em0, en0, wm, wn, li, kh);
     } else {
       gemm_epilogue<ZOUT, RES, 0, 16, false>(p, acc, em0, en0, wm, wn, li, kh);
     }
@@ -690,17 +700,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
           for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[g]);
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[g]);
+          if (F16) {
+            // 16 bytes = the 8 halves of one k-step of v_mfma_f32_32x32x16_f16 (lanes 0-31: k 0-7, lanes 32-63: k 8-15)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (g < 2) piece(g * 4 + j);
+            for (int j = 0; j < 4; ++j)
+              if (g < 2) piece(g * 4 + j);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
               for (int ni = 0; ni < 2; ++ni) {
-                const f32x16 c = (FS && C == 0 && g == 0 && j == 0) ? ini[ni] : acc[mi][ni];
-                acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], c, 0, 0, 0)
-                                   : __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][j], a[mi][j], c, 0, 0, 0);
+                const f32x16 c = (FS && C == 0 && g == 0) ? ini[ni] : acc[mi][ni];
+                const f16x8 ah = __builtin_bit_cast(f16x8, a[mi]), bh = __builtin_bit_cast(f16x8, b[ni]);
+                acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, c, 0, 0, 0);
               }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (g < 2) piece(g * 4 + j);
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                  const f32x16 c = (FS && C == 0 && g == 0 && j == 0) ? ini[ni] : acc[mi][ni];
+                  acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], c, 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][j], a[mi][j], c, 0, 0, 0);
+                }
+            }
           }
         }
         buf ^= 1;
@@ -734,6 +760,25 @@ static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s
   for (int s = 1; s < p.nseg; ++s)
     if (p.seg[s].kpad != kpad || p.seg[s].cin != cin) return false;
   const bool tail = cin != kpad;
+  if (p.f16) {
+    // 4-byte units: 256 halves = 128 units = 4 chunks; LSTM inputs of 200 / 100 halves are padded to 256 / 128 halves
+    if (!ZOUT && p.N % GEMM_BN) return false;
+    if (kpad == 128 && !tail) {
+      hipLaunchKernelGGL((gemm_f32_dma_kernel<ZOUT, RES, 4, false, true>), grid, block, 0, stream, p);
+      return true;
+    }
+    if constexpr (ZOUT) {
+      if (kpad == 128 && tail) {
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4, true, true>), grid, block, 0, stream, p);
+        return true;
+      }
+      if (kpad == 64 && tail) {
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 2, true, true>), grid, block, 0, stream, p);
+        return true;
+      }
+    }
+    return false;
+  }
   if (kpad == 256 && !tail) {
     hipLaunchKernelGGL((gemm_f32_dma_kernel<ZOUT, RES, 8, false>), grid, block, 0, stream, p);
     return true;
@@ -751,7 +796,7 @@ static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s
   return false;
 }
 
-void launch_gemm(const GemmParams& p, hipStream_t stream) {
+bool launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int nblocks_n = (p.N + GEMM_BN - 1) / GEMM_BN;
   const int mblocks = (p.M + GEMM_BM - 1) / GEMM_BM;
   const int total_ids = ((mblocks + 7) / 8) * 8 * nblocks_n;
@@ -766,6 +811,12 @@ void launch_gemm(const GemmParams& p, hipStream_t stream) {
   g = (g / 8) * 8;
   if (g > total_ids) g = total_ids;
   const dim3 grid(g), block(256);
+  if (p.f16) {  // halves: only the DMA kernels exist
+    if (p.seg[0].src == nullptr) return false;
+    if (p.out_mode == 1) return launch_dma<true, false>(p, grid, block, stream);
+    if (p.res_a != nullptr) return launch_dma<false, true>(p, grid, block, stream);
+    return launch_dma<false, false>(p, grid, block, stream);
+  }
   if (p.seg[0].src == nullptr) {  // lifted signal: A is computed in the loader
     hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, block, 0, stream, p);
   } else if (p.out_mode == 1) {
@@ -778,6 +829,7 @@ void launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (!launch_dma<false, false>(p, grid, block, stream))
       hipLaunchKernelGGL((gemm_f32_kernel<false, false, false>), grid, block, 0, stream, p);
   }
+  return true;
 }
 
 }  // namespace chiron

@@ -64,7 +64,15 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
     const int b = (int)(pos / p.T);
     const int t = (int)(pos - (long)b * p.T);
     f32x4 h = {0.f, 0.f, 0.f, 0.f};
-    if (lane < nl) h = *reinterpret_cast<const f32x4*>(p.lasth + ((long)t * p.BP + b) * 2 * H + 4 * lane);
+    if (lane < nl) {
+      if (p.f16) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 hh = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.lasth) + ((long)t * p.BP + b) * 2 * H + 4 * lane);
+        h = (f32x4){(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]};
+      } else {
+        h = *reinterpret_cast<const f32x4*>(p.lasth + ((long)t * p.BP + b) * 2 * H + 4 * lane);
+      }
+    }
     float acc[CHIRON_KMAX];
 #pragma unroll
     for (int k = 0; k < CHIRON_KMAX; ++k) {

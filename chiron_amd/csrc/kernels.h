@@ -66,10 +66,14 @@ struct GemmParams {
   int z_dirs_total;  // out_mode 1: directions in the z buffer (2)
   const int32_t* z_seq_len;  // out_mode 1: [BP] sequence lengths; direction 1 is stored time-reversed per row:
                              //   z[s][b][dir 1] = x-projection of frame seq_len[b]-1-s (tf.reverse_sequence folded in)
-  const float* zero_page;  // >= 256 B of zeros: DMA source of padded rows / K tails
+  const float* zero_page;  // >= 4 KB of zeros: DMA source of padded rows / K tails
+  // f16 = 1 (engine dtype CHIRON_F16): A, Wt and the conv output hold IEEE halves; lda / col0 / cin / kpad / K and
+  // ldo are then counted in 4-BYTE UNITS (two halves) so that the loader geometry is the fp32 one; accumulation,
+  // shift and the z output stay fp32.
+  int f16;
 };
 
-void launch_gemm(const GemmParams& p, hipStream_t stream);
+bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel for this shape / dtype
 
 // ---------------------------------------------------------------------------------------------
 // LSTM recurrence (lstm.hip): one workgroup = 4*NG batch rows x one direction x all T steps.
@@ -87,8 +91,14 @@ struct LstmParams {
   int T, B, BP, H;
   int ndir;              // 2
   int rows_per_wg;       // 4, 8 or 16
+  int f16;               // 1: wfrag holds halves in 4x4x4 fragment order, out (lasth) is written as halves; z stays fp32
 };
 void launch_lstm(const LstmParams& p, hipStream_t stream);
+constexpr int LSTM_KSTEPS16 = 25;  // k-steps of v_mfma_f32_4x4x4_16B_f16 covering K = 100
+
+// relu(sig*a[c] + b[c]) as halves [B*L][C]: res_layer1/conv2a materialised for the f16 path (gemm.hip fuses it into
+// its loader for fp32)
+void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // FC head + CTC (head_ctc.hip)
@@ -101,6 +111,7 @@ struct FcParams {
   const float* bc;     // [K]
   float* logits;       // [B][T][K]
   int T, B, BP, H, K;
+  int f16;  // lasth holds halves
 };
 void launch_fc(const FcParams& p, hipStream_t stream);
 

@@ -183,12 +183,135 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// f16 variant (engine dtype CHIRON_F16): h and W_hh are IEEE halves on v_mfma_f32_4x4x4_16B_f16 (K = 4 per
+// instruction: 25 MFMAs per step instead of 100, W_hh in 50 registers), accumulation, z, gates and the cell state
+// stay fp32; lasth is written as halves for the next layer's f16 GEMM.  Same workgroup shape and A-broadcast
+// scheme: lane (blk, row) keeps h[row][4*(blk + 16q) .. +3], q = 0,1 -- one ds_read_b128 per step.
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int HG16 = 16 * 4 * 8;  // halves per group and buffer
+
+__global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParams p) {
+  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * HG16];
+  __shared__ __attribute__((aligned(16))) float tbuf[LSTM_NW * 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x % p.ndir;
+  const int g0 = blockIdx.x / p.ndir;  // 4-row group of this workgroup
+
+  f16x4 w[LSTM_KSTEPS16];
+  {
+    const f16x4* wf = reinterpret_cast<const f16x4*>(p.wfrag) + ((long)dir * LSTM_NW + wave) * LSTM_KSTEPS16 * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < LSTM_KSTEPS16; ++j) w[j] = wf[j * 64];
+  }
+  for (int i = tid; i < 2 * HG16; i += 64 * LSTM_NW) hbuf[i] = (_Float16)0.f;
+
+  const int unit = wave * 16 + (lane & 15);
+  const int row = lane >> 4;
+  const bool live = unit < p.H;
+  const int lenr = min(p.seq_len[g0 * 4 + row], p.T);
+  int maxlen = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) maxlen = max(maxlen, min(p.seq_len[g0 * 4 + r], p.T));
+  __syncthreads();
+
+  const unsigned outw = p.ndir * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * LSTM_ZCOLS * 4;
+  const unsigned zlane_b = ((g0 * p.ndir + dir) * LSTM_ZCOLS + wave * 64 + lane) * 16;
+  const unsigned ostep = p.BP * outw;
+  const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
+  _Float16* outh = reinterpret_cast<_Float16*>(p.out);
+  float* tw = tbuf + wave * 256;
+  // this lane's cell writes h[row][unit]: k-step j = unit/4 = blk + 16q
+  const int hw = ((((unit >> 2) & 15) * 4 + row) * 2 + (unit >> 6)) * 4 + (unit & 3);
+
+  float c = 0.f, hprev = 0.f;
+  int cur = 0;
+  for (int s = 0; s < maxlen; ++s) {
+    f32x4 z;
+    float touch;
+    {
+      const float* zs = p.z + (size_t)s * zstep;
+      const float* zt = p.z + (size_t)min(s + 2, maxlen - 1) * zstep;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z) : "v"(zlane_b), "s"(zs) : "memory");
+      asm volatile("global_load_dword %0, %1, %2" : "=v"(touch) : "v"(zlane_b), "s"(zt) : "memory");
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const f16x8 hv = *reinterpret_cast<const f16x8*>(hbuf + cur * HG16 + lane * 8);
+    const f16x4 h0 = {hv[0], hv[1], hv[2], hv[3]}, h1 = {hv[4], hv[5], hv[6], hv[7]};
+#define CHIRON_MF16(J)                                                                                     \
+  if ((J) < LSTM_KSTEPS16) {                                                                                \
+    if ((J) & 1)                                                                                            \
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x4f16((J) < 16 ? h0 : h1, w[(J) % LSTM_KSTEPS16], acc1, 4, (J) % 16, 0); \
+    else                                                                                                    \
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x4f16((J) < 16 ? h0 : h1, w[(J) % LSTM_KSTEPS16], acc0, 4, (J) % 16, 0); \
+  }
+    CHIRON_MF16(0) CHIRON_MF16(1) CHIRON_MF16(2) CHIRON_MF16(3) CHIRON_MF16(4) CHIRON_MF16(5) CHIRON_MF16(6) CHIRON_MF16(7)
+    CHIRON_MF16(8) CHIRON_MF16(9) CHIRON_MF16(10) CHIRON_MF16(11) CHIRON_MF16(12) CHIRON_MF16(13) CHIRON_MF16(14) CHIRON_MF16(15)
+    CHIRON_MF16(16) CHIRON_MF16(17) CHIRON_MF16(18) CHIRON_MF16(19) CHIRON_MF16(20) CHIRON_MF16(21) CHIRON_MF16(22) CHIRON_MF16(23)
+    CHIRON_MF16(24)
+#undef CHIRON_MF16
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z), "+v"(touch));
+    const f32x4 v = acc0 + acc1 + z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tw[(r * 16 + (lane & 15)) * 4 + (lane >> 4)] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 q = *reinterpret_cast<const f32x4*>(tw + lane * 4);  // i, j, f, o of (row, unit)
+    const bool act = s < lenr;
+    const float cn = fmaf(fast_sigmoid(q[2]), c, fast_sigmoid(q[0]) * fast_tanh(q[1]));
+    const float hnew = fast_sigmoid(q[3]) * fast_tanh(cn);
+    c = act ? cn : c;
+    hprev = act ? hnew : hprev;
+    if (live) {
+      hbuf[(cur ^ 1) * HG16 + hw] = (_Float16)hprev;
+      const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+      outh[to * ostep + olane] = (_Float16)(act ? hnew : 0.f);
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  for (int s = maxlen; s < p.T; ++s)
+    for (int i = tid; i < 4 * p.H; i += 64 * LSTM_NW) {
+      const int r = i / p.H;
+      const int u = i - r * p.H;
+      outh[((long)s * p.BP + g0 * 4 + r) * outw + dir * p.H + u] = (_Float16)0.f;
+    }
+}
+
+// res_layer1/conv2a for the f16 path: a1[pos][c] = relu(sig[pos]*a[c] + b[c]) as halves
+__global__ __launch_bounds__(256) void lift_f16_kernel(const float* __restrict__ sig, const float* __restrict__ a,
+                                                       const float* __restrict__ b, _Float16* __restrict__ out, long n_pos, int C) {
+  const int c8 = C / 8;  // 8 halves = 16 bytes per thread
+  const long total = n_pos * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pos = i / c8;
+    const int c0 = (int)(i - pos * c8) * 8;
+    const float x = sig[pos];
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)fmaxf(fmaf(x, a[c0 + j], b[c0 + j]), 0.f);
+    *reinterpret_cast<f16x8*>(out + pos * C + c0) = v;
+  }
+}
+
+void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, hipStream_t stream) {
+  hipLaunchKernelGGL(lift_f16_kernel, dim3(256 * 16), dim3(256), 0, stream, sig, a, b, reinterpret_cast<_Float16*>(out), n_pos, C);
+}
+
 void launch_lstm(const LstmParams& p, hipStream_t stream) {
   // hidden = 100 is the only size the reference's shipped models use (rnn.py:23 hidden_num=100)
   const int groups = p.BP / 4;
   const int ng = p.rows_per_wg / 4;
   const dim3 block(64 * LSTM_NW);
-  if (ng == 1)
+  if (p.f16)
+    hipLaunchKernelGGL(lstm16_kernel, dim3(groups * p.ndir), block, 0, stream, p);
+  else if (ng == 1)
     hipLaunchKernelGGL(lstm_kernel<1>, dim3(groups * p.ndir), block, 0, stream, p);
   else if (ng == 2)
     hipLaunchKernelGGL(lstm_kernel<2>, dim3(groups / 2 * p.ndir), block, 0, stream, p);

@@ -89,6 +89,10 @@ typedef struct {
  * (in CHIRON_BN_BATCH mode the pop_mean/pop_var slots are present but unused.) */
 chiron_status chiron_weights_size(const chiron_model_desc* desc, size_t* n_floats);
 
+/* CHIRON_F32: exact-fp32 path (fp32 MFMA), the parity path: logits within 1e-4 of the reference arithmetic.
+ * CHIRON_F16: activations, weights and the recurrent h as IEEE halves on the f16 MFMA instructions; accumulation,
+ *             the LSTM pre-activations z, gates, cell state, logits and both CTC decoders stay fp32 (BASELINE
+ *             configs[4]).  Logits stay within 0.08 of the fp32 engine (tests/test_gpu_parity.py).            */
 typedef enum { CHIRON_F32 = 0, CHIRON_F16 = 1 } chiron_dtype;
 
 typedef struct {

@@ -323,6 +323,39 @@ def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
     monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
 
 
+def test_f16_path_tolerance_vs_f32(dna, rna):
+    """BASELINE configs[4]: fp16 conv + LSTM on the f16 MFMA instructions, fp32 accumulation / gates / CTC.
+    Tolerance check against the fp32 engine on identical inputs (the fp32 engine is itself within 1e-4 of the
+    oracle): logits within 0.08 absolute (fp16 has 11 bits of mantissa and three stacked BiLSTMs in between), the
+    greedy base strings identical on >= 97 % of the windows and never further than 2 edits apart."""
+    import difflib
+    for (spec, w), L, jump, n in ((dna, 400, 390, 150), (rna, 500, 490, 40)):
+        x, ln = _windows(jump * (n - 1) + 123, L, jump, seed=41)
+        B = x.shape[0]
+        ln = ln.copy()
+        ln[1] = L // 3                                           # one ragged row besides the short last window
+        with ca.Engine(spec, w, max_batch=B, segment_len=L) as e32:
+            sl = ca.seq_len_for_engine(ln, e32.ratio)
+            r32 = e32.infer(x, sl, want_prob=True, want_logits=True)
+        with ca.Engine(spec, w, max_batch=B, segment_len=L, dtype="fp16") as e16:
+            r16 = e16.infer(x, sl, want_prob=True, want_logits=True)
+            again = e16.infer(x, sl, want_logits=True)
+            assert np.array_equal(again.logits, r16.logits)      # deterministic
+        assert np.isfinite(r16.logits).all()
+        T = r32.logits.shape[1]
+        mask = np.arange(T)[None, :] < sl[:, None]
+        err = np.abs(r16.logits - r32.logits)[mask].max()
+        assert err < 0.08, err
+        rows16 = _check_decode(r16, r16.logits, sl, B)            # the decoders run in fp32 on the f16 logits
+        rows32 = _check_decode(r32, r32.logits, sl, B)
+        same = sum(a == b for a, b in zip(rows16, rows32))
+        assert same >= 0.97 * B, (same, B)
+        for a, b in zip(rows16, rows32):
+            if a != b:
+                sm = difflib.SequenceMatcher(None, a, b, autojunk=False)
+                assert max(len(a), len(b)) - sum(m.size for m in sm.get_matching_blocks()) <= 2
+
+
 def test_chiron_call_cli_on_fast5_folder(tmp_path):
     """BASELINE configs[0] plumbing: `chiron call` on a folder of fast5 files with model/DNA_default,
     batch=100, greedy.  The trained weights are stripped from the reference tree, so the CLI runs with

@@ -15,12 +15,12 @@ import chiron_amd as ca
 from chiron_amd import signal_io
 
 
-def run(name, spec, L, jump, B, beam, steps=6):
+def run(name, spec, L, jump, B, beam, steps=6, dtype="fp32"):
     w = ca.synthetic_weights(spec, seed=1234)
     sig = ca.synthetic_signal(1, jump * (B - 1) + L, seed=5)[0]
     x, ln = signal_io.window_signal(sig, 0, jump, L)
     x, ln = x[:B], ln[:B]
-    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=2, max_beam=beam) as eng:
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=2, max_beam=beam, dtype=dtype) as eng:
         sl = ca.seq_len_for_engine(ln, eng.ratio)
         for _ in range(2):
             eng.infer(x, sl, beam_width=beam)
@@ -43,13 +43,18 @@ def run(name, spec, L, jump, B, beam, steps=6):
         st = eng.profile_read()
         eng.profile(False)
     bases_per_window = jump / (4000.0 / 450.0) if "DNA" in name else jump / (3012.0 / 70.0)
-    print(json.dumps({"config": name, "batch": B, "segment_len": L, "jump": jump, "beam": beam, "T": spec.output_len(L),
+    print(json.dumps({"config": name, "dtype": dtype, "batch": B, "segment_len": L, "jump": jump, "beam": beam, "T": spec.output_len(L),
                       "ms_per_batch": round(dt / steps * 1e3, 3), "windows_per_s": round(steps * B / dt, 1),
                       "decoded_bases_per_s": round(nb / dt, 1),
                       "kernels_ms": {k: round(v["total_ms"] / v["launches"], 4) for k, v in st.items()}}))
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "f16":  # BASELINE configs[4]: fp16 conv + LSTM, batch 4096 (and 1100 for comparison)
+        run("DNA_default seg400 jump390 b4096 greedy f16", ca.dna_default_spec(), 400, 390, 4096, 0, dtype="fp16")
+        run("DNA_default seg400 jump390 b1100 greedy f16", ca.dna_default_spec(), 400, 390, 1100, 0, dtype="fp16")
+        run("DNA_default seg400 jump390 b4096 greedy f32", ca.dna_default_spec(), 400, 390, 4096, 0)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "batches":  # kernel time vs batch size (workgroup-count effects)
         for B in [int(v) for v in sys.argv[2:]]:
             run("DNA_default seg400 jump390 b%d greedy" % B, ca.dna_default_spec(), 400, 390, B, 0, steps=4)
