@@ -129,6 +129,11 @@ struct BlockPlan {
   float *lift_a = nullptr, *lift_b = nullptr;  // lift: conv2a folded scale/shift
   float* res_a = nullptr;                      // lift: branch1 folded scale
   ConvGemmPlan ga, gb, gc;                     // conv2a (non-lift), conv2b, conv2c(+conv1)
+  // bn_mode = batch (cnn.py:166-188): the GEMM weights above are raw, gc holds conv2c alone, g1 the 1x1 branch1 conv;
+  // scale / offset of the four BN sites (conv1 only when i_bn)
+  ConvGemmPlan g1;
+  bool i_bn = false;
+  float *bn_scale[4] = {nullptr, nullptr, nullptr, nullptr}, *bn_offset[4] = {nullptr, nullptr, nullptr, nullptr};  // conv1, 2a, 2b, 2c
 };
 
 struct LstmPlan {
@@ -148,7 +153,8 @@ struct Slot {
   hipStream_t stream = nullptr;
   float* sig = nullptr;
   int32_t* seq = nullptr;
-  float* act[3] = {nullptr, nullptr, nullptr};
+  float* act[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 3 in population mode, 5 in batch-BN mode
+  double* bn_sums = nullptr;  // batch-BN mode: two sets of [2][C] sums
   float* z = nullptr;
   float* lasth[2] = {nullptr, nullptr};
   float* logits = nullptr;
@@ -185,6 +191,7 @@ struct chiron_engine {
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
   int lstm_rows = 4;   // batch rows per recurrence workgroup (4, 8 or 16)
+  bool bn_batch = false;  // desc.bn_mode == CHIRON_BN_BATCH
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
   int kq = GEMM_BK;    // K padding quantum in elements: one LDS chunk = 128 bytes per row (32 floats / 64 halves)
   std::vector<BlockPlan> blocks;
@@ -248,9 +255,9 @@ static chiron_status upload_gemm(chiron_engine* e, ConvGemmPlan* g, const std::v
 
 static chiron_status build_plans(chiron_engine* e, const float* w) {
   const chiron_model_desc& d = e->desc;
-  if (d.bn_mode != CHIRON_BN_POPULATION)
-    return fail(CHIRON_ERR_INVALID, "bn_mode=batch (HEAD simple_global_bn) is not implemented in this build; "
-                                    "the shipped checkpoints use population statistics");
+  const bool batch = d.bn_mode == CHIRON_BN_BATCH;
+  e->bn_batch = batch;
+  if (batch && e->f16) return fail(CHIRON_ERR_INVALID, "bn_mode=batch is implemented for dtype f32 only");
   if (e->f16) {
     for (int bi = 0; bi < d.n_blocks; ++bi)
       if (d.blocks[bi].out_channels % GEMM_BN || (d.blocks[bi].in_channels != 1 && d.blocks[bi].in_channels % 64))
@@ -270,32 +277,46 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
     bp.t_in = t;
     same_pad(t, b.k, b.stride, &bp.t_out, &bp.left);
     const int ci = b.in_channels, co = b.out_channels;
+    chiron_status st;
+    bp.i_bn = b.i_bn != 0;
+    // one BN site: population statistics fold into the weights; batch statistics leave the weights raw and keep
+    // scale / offset for bn_batch.hip
+    auto bn_site = [&](int site, BnFold* f) -> chiron_status {
+      if (batch) {
+        f->inv.assign(co, 1.0f);
+        f->sh.assign(co, 0.0f);
+        std::vector<float> sc(p, p + co), of(p + co, p + 2 * co);
+        chiron_status r = dev_upload(e, &bp.bn_scale[site], sc);
+        if (r == CHIRON_OK) r = dev_upload(e, &bp.bn_offset[site], of);
+        p += 4 * co;
+        return r;
+      }
+      *f = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
+      p += 4 * co;
+      return CHIRON_OK;
+    };
     const float* W1 = p;
     p += (size_t)ci * co;
     BnFold f1;
     if (b.i_bn) {
-      f1 = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
-      p += 4 * co;
+      if ((st = bn_site(0, &f1))) return st;
     } else {
       f1.inv.assign(co, 1.0f);
       f1.sh.assign(co, 0.0f);
     }
     const float* W2a = p;
     p += (size_t)ci * co;
-    BnFold f2a = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
-    p += 4 * co;
+    BnFold f2a, f2b, f2c;
+    if ((st = bn_site(1, &f2a))) return st;
     const float* W2b = p;
     p += (size_t)b.k * co * co;
-    BnFold f2b = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
-    p += 4 * co;
+    if ((st = bn_site(2, &f2b))) return st;
     const float* W2c = p;
     p += (size_t)co * co;
-    BnFold f2c = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
-    p += 4 * co;
+    if ((st = bn_site(3, &f2c))) return st;
 
     const int Npad = roundup(co, GEMM_BN);
     const int cop = roundup(co, e->kq);
-    chiron_status st;
     // conv2b: Wt[n][tap*cop + c] = W2b[tap][c][n] * inv2b[n]
     {
       const int K = b.k * cop;
@@ -336,7 +357,23 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
         }
         if ((st = upload_gemm(e, &bp.ga, Wt, sh, co, Npad, K))) return st;
       }
-      {
+      if (batch) {
+        // separate GEMMs: each branch is normalised with its own batch statistics before the add
+        {
+          const int K = cop;
+          std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
+          for (int n = 0; n < co; ++n)
+            for (int c = 0; c < co; ++c) Wt[(size_t)n * K + c] = W2c[(size_t)c * co + n];
+          if ((st = upload_gemm(e, &bp.gc, Wt, sh, co, Npad, K))) return st;
+        }
+        {
+          const int K = cip;
+          std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
+          for (int n = 0; n < co; ++n)
+            for (int c = 0; c < ci; ++c) Wt[(size_t)n * K + c] = W1[(size_t)c * co + n];
+          if ((st = upload_gemm(e, &bp.g1, Wt, sh, co, Npad, K))) return st;
+        }
+      } else {
         // conv2c and branch1/conv1 fused along K: [conv2b output | block input]
         const int K = cop + cip;
         std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
@@ -445,15 +482,16 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   const size_t B = e->maxB, BP = e->BP, L = e->L, T = e->T, H = e->H, K = e->K;
   size_t tmax = 0, cmax = 0;
   for (const BlockPlan& b : e->blocks) {
-    if (!b.lift || e->f16) tmax = std::max<size_t>(tmax, b.t_in);  // f16 materialises the lifted conv2a at input resolution
+    if (!b.lift || e->f16 || e->bn_batch) tmax = std::max<size_t>(tmax, b.t_in);  // f16 / batch-BN materialise the lifted conv2a
     tmax = std::max<size_t>(tmax, b.t_out);
     cmax = std::max<size_t>(cmax, b.c);
   }
   chiron_status st;
   if ((st = dev_alloc(e, (void**)&s->sig, B * L * 4, true))) return st;
   if ((st = dev_alloc(e, (void**)&s->seq, BP * 4, true))) return st;
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < (e->bn_batch ? 5 : 3); ++i)
     if ((st = dev_alloc(e, (void**)&s->act[i], B * tmax * cmax * (e->f16 ? 2 : 4), false))) return st;
+  if (e->bn_batch && (st = dev_alloc(e, (void**)&s->bn_sums, 2 * 2 * cmax * sizeof(double), true))) return st;
   if ((st = dev_alloc(e, (void**)&s->z, T * BP * 2 * LSTM_ZCOLS * 4, true))) return st;
   for (int i = 0; i < 2; ++i)
     if ((st = dev_alloc(e, (void**)&s->lasth[i], T * BP * 2 * H * 4, true))) return st;
@@ -612,7 +650,82 @@ static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
   return launch_gemm(g, stream);
 }
 
+// bn_mode = batch: every BN site is raw conv -> batch moments -> normalise (cnn.py:166-188), nothing folds.
+static bool run_cnn_batch_bn(chiron_engine* e, Slot* s, int B, const float* sig) {
+  bool ok = true;
+  int xi = -1;
+  const float* x = nullptr;
+  for (const BlockPlan& b : e->blocks) {
+    float* buf[4];
+    for (int i = 0, j = 0; i < 5 && j < 4; ++i)
+      if (i != xi) buf[j++] = s->act[i];
+    float *A = buf[0], *Bf = buf[1], *Cf = buf[2], *D = buf[3];
+    const int cop = roundup(b.c, e->kq), C = b.c;
+    const long Min = (long)B * b.t_in, Mout = (long)B * b.t_out;
+    double* s0 = s->bn_sums;
+    double* s1 = s->bn_sums + 2 * C;
+    GemmParams g;
+    Prof pr(e, s, PN_CONV, 2.0 * ((double)Min * b.c_in * C + (double)Mout * (b.k * C + C + b.c_in) * C), 4.0 * (Min + 3.0 * Mout) * C * 3);
+    // conv2a + BN + ReLU
+    if (b.lift) {
+      launch_rank1_conv(sig, b.lift_a, A, Min, b.t_in, e->L, 1, C, s->stream);
+    } else {
+      init_gemm(&g, e, b.ga, B);
+      g.M = (int)Min;
+      g.T_out = b.t_in;
+      g.nseg = 1;
+      g.seg[0] = GemmSeg{x, b.c_in, 0, b.c_in, roundup(b.c_in, e->kq), b.t_in, 1, 0, 0};
+      g.out = A;
+      g.ldo = C;
+      ok &= launch(e, g, s->stream);
+    }
+    launch_bn_stats(A, Min, C, s0, s->stream);
+    launch_bn_apply(A, s0, b.bn_scale[1], b.bn_offset[1], Min, C, 1, nullptr, nullptr, nullptr, nullptr, s->stream);
+    // conv2b + BN + ReLU
+    init_gemm(&g, e, b.gb, B);
+    g.M = (int)Mout;
+    g.T_out = b.t_out;
+    g.nseg = b.k;
+    for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{A, C, 0, C, cop, b.t_in, b.stride, j - b.left, 0};
+    g.out = Bf;
+    g.ldo = C;
+    ok &= launch(e, g, s->stream);
+    launch_bn_stats(Bf, Mout, C, s0, s->stream);
+    launch_bn_apply(Bf, s0, b.bn_scale[2], b.bn_offset[2], Mout, C, 1, nullptr, nullptr, nullptr, nullptr, s->stream);
+    // conv2c (+ BN), branch1 conv1 (+ BN iff i_bn), add, ReLU
+    init_gemm(&g, e, b.gc, B);
+    g.M = (int)Mout;
+    g.T_out = b.t_out;
+    g.nseg = 1;
+    g.seg[0] = GemmSeg{Bf, C, 0, C, cop, b.t_out, 1, 0, 0};
+    g.out = Cf;
+    g.ldo = C;
+    ok &= launch(e, g, s->stream);
+    launch_bn_stats(Cf, Mout, C, s0, s->stream);
+    if (b.lift) {
+      launch_rank1_conv(sig, b.res_a, D, Mout, b.t_out, e->L, b.stride, C, s->stream);
+    } else {
+      init_gemm(&g, e, b.g1, B);
+      g.M = (int)Mout;
+      g.T_out = b.t_out;
+      g.nseg = 1;
+      g.seg[0] = GemmSeg{x, b.c_in, 0, b.c_in, roundup(b.c_in, e->kq), b.t_in, b.stride, 0, 0};
+      g.out = D;
+      g.ldo = C;
+      ok &= launch(e, g, s->stream);
+    }
+    if (b.i_bn) launch_bn_stats(D, Mout, C, s1, s->stream);
+    launch_bn_apply(Cf, s0, b.bn_scale[3], b.bn_offset[3], Mout, C, 1, D, b.i_bn ? s1 : nullptr, b.bn_scale[0], b.bn_offset[0], s->stream);
+    x = Cf;
+    for (int i = 0; i < 5; ++i)
+      if (s->act[i] == Cf) xi = i;
+  }
+  s->sig_used = x;
+  return ok;
+}
+
 static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
+  if (e->bn_batch) return run_cnn_batch_bn(e, s, B, sig);
   bool ok = true;
   float* x = nullptr;  // block input (channels-last [B*T][C])
   int xi = -1;         // which act buffer holds x

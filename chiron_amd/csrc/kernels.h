@@ -157,4 +157,12 @@ struct PathProbParams {
 };
 void launch_path_prob(const PathProbParams& p, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// batch-statistics BatchNorm (bn_batch.hip): cnn.py:166-188 simple_global_bn
+// ---------------------------------------------------------------------------------------------
+void launch_bn_stats(const float* x, long M, int C, double* sums /* [2][C] */, hipStream_t stream);
+void launch_bn_apply(float* x, const double* sums, const float* scale, const float* offset, long M, int C, int relu, const float* add,
+                     const double* add_sums, const float* add_scale, const float* add_offset, hipStream_t stream);
+void launch_rank1_conv(const float* sig, const float* w, float* out, long n_pos, int T_out, int L, int stride, int C, hipStream_t stream);
+
 }  // namespace chiron

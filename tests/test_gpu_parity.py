@@ -323,6 +323,33 @@ def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
     monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
 
 
+def test_batch_statistics_bn_mode(built):
+    """HEAD's simple_global_bn (cnn.py:166-188): BatchNorm with the moments of THIS batch (biased variance, all
+    rows and positions).  The result of a row depends on what else is in the batch, so the comparison uses the
+    oracle on exactly the same batch; both topologies (DNA: stride 1; RNA: k = 13, stride 5 in block 1)."""
+    from oracle import nn_oracle
+    for mk, L, jump in ((ca.dna_default_spec, 400, 390), (ca.rna_default_spec, 500, 490)):
+        spec = mk(bn_mode="batch")
+        w = ca.synthetic_weights(spec, seed=23)
+        x, ln = _windows(jump * 12 + 150, L, jump, seed=8)
+        B = x.shape[0]
+        with ca.Engine(spec, w, max_batch=B + 5, segment_len=L) as eng:
+            sl = ca.seq_len_for_engine(ln, eng.ratio)
+            res = eng.infer(x, sl, want_prob=True, want_logits=True)
+            ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+            err = np.abs(res.logits.astype(np.float64) - ref).max()
+            assert err < TOL, err
+            _check_decode(res, res.logits, sl, B)
+            # batch statistics: dropping a row changes every other row (population mode would not)
+            sub = eng.infer(x[:-1], sl[:-1], want_logits=True)
+            assert np.abs(sub.logits - res.logits[:-1]).max() > 1e-6
+            ref2, _ = nn_oracle.inference(x[:-1], sl[:-1], spec.to_dict(), w, dtype=np.float64)
+            assert np.abs(sub.logits.astype(np.float64) - ref2).max() < TOL
+    with pytest.raises(_lib.ChironError):                      # not offered for the f16 dtype
+        ca.Engine(ca.dna_default_spec(bn_mode="batch"), ca.synthetic_weights(ca.dna_default_spec(bn_mode="batch"), seed=1),
+                  max_batch=4, segment_len=400, dtype="fp16")
+
+
 def test_f16_path_tolerance_vs_f32(dna, rna):
     """BASELINE configs[4]: fp16 conv + LSTM on the f16 MFMA instructions, fp32 accumulation / gates / CTC.
     Tolerance check against the fp32 engine on identical inputs (the fp32 engine is itself within 1e-4 of the
