@@ -15,7 +15,7 @@ def family(name):
     n = name.split("(")[0]
     if "gemm_f32_dma_kernel" in n or "gemm_f32_kernel" in n:
         return n.replace("void ", "").replace("chiron::", "").strip()
-    for key in ("lstm_kernel", "fc_kernel", "greedy_kernel", "beam_kernel", "scan_kernel", "scatter_kernel"):
+    for key in ("lstm16_kernel", "lstm_kernel", "fc_kernel", "beam64_kernel", "greedy_kernel", "beam_kernel", "scan_kernel", "scatter_kernel"):
         if key in n:
             return key
     return None
@@ -30,7 +30,7 @@ def main():
             if f:
                 acc[f][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"_note": "mean per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction)",
-           "_command": "tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 3 --warmup 1 --slots 1"}
+           "_command": "tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 3 --warmup 1 --slots 1 --no-cpu-baseline --no-f16"}
     for f, c in acc.items():
         m = {k: sum(v) / len(v) for k, v in c.items()}
         rec = {"launches_sampled": len(c.get("FETCH_SIZE", c.get("SQ_WAVE_CYCLES", [])))}
