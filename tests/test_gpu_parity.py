@@ -383,6 +383,30 @@ def test_f16_path_tolerance_vs_f32(dna, rna):
                 assert max(len(a), len(b)) - sum(m.size for m in sm.get_matching_blocks()) <= 2
 
 
+def test_predict_signature_served_from_the_engine(dna):
+    """export_test.py:103-112 through chiron_amd.serve: the engine behind the local PREDICT endpoint, beam search
+    decode as the exported graph does (export_test.py:36-39), concurrent requests on two slots."""
+    from chiron_amd import serve
+    spec, w = dna
+    x, ln = _windows(390 * 30 + 200, 400, 390, seed=51)
+    B = x.shape[0]
+    with ca.Engine(spec, w, max_batch=16, segment_len=400, n_slots=2, max_beam=50) as eng:
+        direct = [eng.infer(x[a:a + 16], ca.seq_len_for_engine(ln[a:a + 16], eng.ratio), beam_width=50, want_prob=True,
+                            want_logits=True) for a in range(0, B, 16)]
+        with serve.PredictServer(eng, ("127.0.0.1", 0), beam_width=50) as srv, serve.PredictClient(srv.address, concurrency=3) as c:
+            assert c.signature()["max_batch"] == 16
+            out = c.predict(x, ln)                                # 31 rows: two engine batches behind one request
+            futs = [c.predict_future(x[i:i + 5], ln[i:i + 5], want_logits=True) for i in range(0, 30, 5)]
+            parts = [f.result() for f in futs]
+    assert np.array_equal(out["logits"], np.concatenate([d.logits for d in direct]))
+    assert np.array_equal(out["values"], np.concatenate([d.decoded.values for d in direct]))
+    rows = np.concatenate([d.decoded.indices[:, 0] + 16 * k for k, d in enumerate(direct)])
+    assert np.array_equal(out["indices"][:, 0], rows) and out["dense_shape"][0] == B
+    assert np.array_equal(out["log_prob"], np.concatenate([d.log_prob for d in direct]))
+    for i, p in zip(range(0, 30, 5), parts):                      # rows are independent: small requests agree with the big one
+        assert np.array_equal(p["logits"], out["logits"][i:i + 5])
+
+
 def test_chiron_call_cli_on_fast5_folder(tmp_path):
     """BASELINE configs[0] plumbing: `chiron call` on a folder of fast5 files with model/DNA_default,
     batch=100, greedy.  The trained weights are stripped from the reference tree, so the CLI runs with
