@@ -67,6 +67,7 @@ SYMBOLS = [
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("chiron_engine_profile", C.c_int, [C.c_void_p, C.c_int32]),
     ("chiron_engine_profile_read", C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
+    ("chiron_parse_signal_text", C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("chiron_assemble", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.POINTER(C.c_int64)]),
     ("chiron_last_error", C.c_char_p, []),

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/chiron_amd.h"
@@ -76,5 +77,53 @@ extern "C" chiron_status chiron_assemble(const uint8_t* bases, const int64_t* se
       if (qs_sum && seg_qs) qs_sum[b * cap + colx] += q;
     }
   }
+  return CHIRON_OK;
+}
+
+// chiron_input.py:527-539 read_signal(): whitespace separated numbers -> float32 (through double, as Python does)
+extern "C" chiron_status chiron_parse_signal_text(const char* text, size_t len, float* out, size_t cap, size_t* n_out) {
+  if (!text || !out || !n_out) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_parse_signal_text: null argument");
+  const char* p = text;
+  const char* end = text + len;
+  size_t n = 0;
+  auto is_ws = [](char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\f' || c == '\v'; };
+  while (true) {
+    while (p < end && is_ws(*p)) ++p;
+    if (p >= end) break;
+    const char* tok = p;
+    // fast path: plain (signed) decimal integers, which is what extract_sig_ref writes
+    bool neg = false;
+    if (*p == '-' || *p == '+') {
+      neg = *p == '-';
+      ++p;
+    }
+    long long v = 0;
+    int digits = 0;
+    while (p < end && *p >= '0' && *p <= '9' && digits < 15) {
+      v = v * 10 + (*p - '0');
+      ++p;
+      ++digits;
+    }
+    double d;
+    if (digits > 0 && (p == end || is_ws(*p))) {
+      d = neg ? -(double)v : (double)v;
+    } else {
+      // general number: copy the token (strtod needs a terminator) and let the C library decide
+      const char* q = tok;
+      while (q < end && !is_ws(*q)) ++q;
+      char buf[64];
+      const size_t tl = (size_t)(q - tok);
+      if (tl >= sizeof(buf)) return chiron::set_error(CHIRON_ERR_INVALID, "could not convert string to float: token of %zu characters", tl);
+      memcpy(buf, tok, tl);
+      buf[tl] = 0;
+      char* stop = nullptr;
+      d = strtod(buf, &stop);
+      if (stop != buf + tl || tl == 0) return chiron::set_error(CHIRON_ERR_INVALID, "could not convert string to float: '%s'", buf);
+      p = q;
+    }
+    if (n >= cap) return chiron::set_error(CHIRON_ERR_OVERFLOW, "chiron_parse_signal_text: more than %zu values", cap);
+    out[n++] = (float)d;
+  }
+  *n_out = n;
   return CHIRON_OK;
 }

@@ -9,7 +9,9 @@ Deliberate divergences from HEAD, each listed in SURVEY.md appendix D:
   Q3 regroup orders a read's pieces by within-file window index (HEAD's key shadowing scrambles
      multi-batch reads); Q4 no debug prints; Q5 each file is parsed once; Q6 sorted file order.
 """
+import collections
 import os
+from concurrent.futures import ThreadPoolExecutor
 import sys
 import time
 from collections import namedtuple
@@ -287,6 +289,14 @@ def evaluation(FLAGS, engine=None, file_list=None):
     inflight = [None] * engine.n_slots
     results = {}
     step = [0]
+    # The reference overlaps reading, inference and decoding with TF queue runners (chiron_eval.py:304-368, :465-522).
+    # Here: a pool of reader threads parses / windows the next files while the engine works (the native text parser
+    # and zlib release the GIL), and finished reads are assembled and written on a second pool; the main thread only
+    # packs batches and talks to the engine.  Batches are packed in file order, so results do not depend on timing.
+    n_threads = max(1, int(getattr(FLAGS, "threads", 0) or 4))
+    readers = ThreadPoolExecutor(max_workers=n_threads)
+    finishers = ThreadPoolExecutor(max_workers=max(1, n_threads // 2))
+    finishing = []
 
     def drain(slot):
         if inflight[slot] is None:
@@ -295,7 +305,7 @@ def evaluation(FLAGS, engine=None, file_list=None):
         res = engine.collect(slot)
         inflight[slot] = None
         for name, reads, qs_list, meta in collector.add_batch(batch, res, want_qs):
-            results[name] = finish_read(name, reads, qs_list, FLAGS, meta[0], meta[1])
+            finishing.append((name, finishers.submit(finish_read, name, reads, qs_list, FLAGS, meta[0], meta[1])))
 
     def launch(batch):
         slot = step[0] % engine.n_slots
@@ -304,24 +314,38 @@ def evaluation(FLAGS, engine=None, file_list=None):
         engine.submit(slot, batch.x, batch.seq_len, beam_width=FLAGS.beam, want_prob=want_qs)
         inflight[slot] = batch
 
-    for name in files:
-        if (not name.endswith(".signal")) and (not name.endswith(".fast5")):
-            continue
+    def load(name):
         t0 = time.time()
         ds = signal_io.read_data_for_eval(os.path.join(file_dir, name), FLAGS.start, seg_length=FLAGS.segment_len,
                                           step=FLAGS.jump, reverse_fast5=getattr(FLAGS, "reverse_fast5", False))
-        collector.expect(name, ds.reads_n, (t0, time.time() - t0))
-        if ds.reads_n == 0:
-            results[name] = finish_read(name, [], np.empty((0, 1)), FLAGS, t0, time.time() - t0)
-            collector.val.pop(name, None)
-            continue
-        for batch in packer.add_read(name, ds.event, ds.event_length):
-            launch(batch)
-    last = packer.flush()
-    if last is not None:
-        launch(last)
-    for slot in range(engine.n_slots):
-        drain((step[0] + slot) % engine.n_slots)
+        return ds, t0, time.time() - t0
+
+    names = [n for n in files if n.endswith(".signal") or n.endswith(".fast5")]
+    ahead = collections.deque()
+    nxt = 0
+    try:
+        for name in names:
+            while nxt < len(names) and len(ahead) < 2 * n_threads:
+                ahead.append(readers.submit(load, names[nxt]))
+                nxt += 1
+            ds, t0, t_read = ahead.popleft().result()
+            collector.expect(name, ds.reads_n, (t0, t_read))
+            if ds.reads_n == 0:
+                results[name] = finish_read(name, [], np.empty((0, 1)), FLAGS, t0, t_read)
+                collector.val.pop(name, None)
+                continue
+            for batch in packer.add_read(name, ds.event, ds.event_length):
+                launch(batch)
+        last = packer.flush()
+        if last is not None:
+            launch(last)
+        for slot in range(engine.n_slots):
+            drain((step[0] + slot) % engine.n_slots)
+        for name, fut in finishing:
+            results[name] = fut.result()
+    finally:
+        readers.shutdown(wait=True)
+        finishers.shutdown(wait=True)
     if own_engine:
         engine.close()
     return results

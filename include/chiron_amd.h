@@ -189,6 +189,14 @@ chiron_status chiron_engine_profile_read(chiron_engine* e, chiron_kernel_stat* s
 chiron_status chiron_assemble(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs,
                               int32_t kernal, double* counts, double* qs_sum, int64_t cap, int64_t* out_len);
 
+/* Host-side reader of the reference's raw-signal text format: chiron_input.py:527-539 read_signal() --
+ * `f.read().split()` converted to float32 -- whitespace/newline separated numbers.  Each token is parsed as a
+ * C double (like Python's float()) and then narrowed to float32, so the values equal numpy's conversion.
+ * out holds up to cap values; *n_out receives the number parsed.  A token that is not a number ->
+ * CHIRON_ERR_INVALID (the reference raises ValueError); more than cap values -> CHIRON_ERR_OVERFLOW.
+ * Pure host code: callable without a GPU and from several threads at once (it does not touch Python). */
+chiron_status chiron_parse_signal_text(const char* text, size_t len, float* out, size_t cap, size_t* n_out);
+
 const char* chiron_last_error(void);
 int32_t chiron_abi_version(void);
 

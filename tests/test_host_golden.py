@@ -237,3 +237,27 @@ def test_read_collector_orders_pieces_by_window_index():
     name, reads, qs_list, meta = done[0]
     assert [int(r[0]) for r in reads] == [i % 4 for i in range(9)]
     assert qs_list.ravel().tolist() == list(map(float, range(9)))
+
+
+def test_native_signal_text_parser_equals_numpy(built, tmp_path):
+    """chiron_parse_signal_text (C ABI) vs the numpy conversion of chiron_input.py:527-539 on integers, floats,
+    exponents, mixed whitespace, empty input; a bad token raises like the reference's float()."""
+    import ctypes as C
+    from chiron_amd import _lib, signal_io
+    rng = np.random.RandomState(5)
+    ints = " ".join(str(int(v)) for v in rng.randint(-2000, 2000, size=5000))
+    floats = "\n".join(repr(float(v)) for v in rng.randn(3000) * 1e3) + "\t1e-3  -2.5E+4 +7 .5 5. nan inf\r\n"
+    for text in (ints, floats, "", "   \n", "42", ints + "\n" + floats):
+        p = tmp_path / "t.signal"
+        p.write_text(text)
+        got = signal_io.read_signal(str(p))
+        want = np.asarray(text.split(), dtype=np.float32)
+        assert got.dtype == np.float32 and got.shape == want.shape
+        assert np.array_equal(got, want, equal_nan=True)
+    p.write_text("1 2 x3 4")
+    with pytest.raises(ValueError, match="could not convert"):
+        signal_io.read_signal(str(p))
+    lib = _lib.load()
+    out = np.empty(2, np.float32)
+    n = C.c_size_t()
+    assert lib.chiron_parse_signal_text(b"1 2 3", 5, out.ctypes.data_as(C.c_void_p), 2, C.byref(n)) == _lib.ERR_OVERFLOW

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end `chiron call` throughput on synthetic reads (host pipeline + engine): N reads x 100k samples written
+as .signal files, then chiron_amd.eval.evaluation with the DNA preset.  usage: e2e_bench.py [n_reads] [beam] [fmt]"""
+import cProfile
+import os
+import pstats
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import chiron_amd as ca
+from chiron_amd import eval as ce
+
+
+def main():
+    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    beam = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    prof = len(sys.argv) > 3 and sys.argv[3] == "profile"
+    d = tempfile.mkdtemp(prefix="e2e_")
+    inp = os.path.join(d, "in")
+    os.makedirs(inp)
+    sig = ca.synthetic_signal(n_reads, 100000, seed=77)
+    t0 = time.time()
+    for i in range(n_reads):
+        with open(os.path.join(inp, "read%04d.signal" % i), "w") as f:
+            f.write(" ".join(str(int(v)) for v in sig[i]))
+    t_write = time.time() - t0
+
+    class F(object):
+        input, output, model = inp, os.path.join(d, "out"), "synthetic"
+        start, batch_size, segment_len, jump = 0, 1100, 400, 390
+        extension, concise, mode, recursive = "fastq", False, "dna", True
+    F.beam = beam
+    spec = ca.dna_default_spec()
+    w = ca.synthetic_weights(spec, seed=1234)
+    with ca.Engine(spec, w, max_batch=1100, segment_len=400, n_slots=2, max_beam=beam) as eng:
+        ce.evaluation(F, engine=eng)          # warm-up (page cache, first launches)
+        shutil.rmtree(F.output)
+        pr = cProfile.Profile() if prof else None
+        t0 = time.time()
+        if pr:
+            pr.enable()
+        out = ce.evaluation(F, engine=eng)
+        if pr:
+            pr.disable()
+        dt = time.time() - t0
+    windows = n_reads * 257
+    print("reads %d  windows %d  beam %d : %.2f s  -> %.0f windows/s, %.1f kbases/s (signal-normalised); input written in %.1f s"
+          % (n_reads, windows, beam, dt, windows / dt, windows * 390 / (4000 / 450.0) / 1000 / dt, t_write))
+    if pr:
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+    shutil.rmtree(d)
+
+
+if __name__ == "__main__":
+    main()
