@@ -17,7 +17,7 @@ CLASSES = 5
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
-F32, F16 = 0, 1
+F32, F16, F32_SPLIT = 0, 1, 2
 X_ON_DEVICE, WANT_PROB, WANT_LOGITS, NO_DECODE_COPY = 1, 2, 4, 8
 KERNAL_GLUE, KERNAL_STICK = 1, 2
 

@@ -193,6 +193,8 @@ struct chiron_engine {
   int lstm_rows = 4;   // batch rows per recurrence workgroup (4, 8 or 16)
   bool bn_batch = false;  // desc.bn_mode == CHIRON_BN_BATCH
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
+  bool split = false;  // opts.dtype == CHIRON_F32_SPLIT: fp32 values as hi/lo half pairs on the f16 matrix cores (GEMMs only)
+  int lasth_ld = 0;    // elements per lasth row (2H; split: rounded up to whole 32-element blocks)
   int kq = GEMM_BK;    // K padding quantum in elements: one LDS chunk = 128 bytes per row (32 floats / 64 halves)
   std::vector<BlockPlan> blocks;
   std::vector<LstmPlan> lstm;
@@ -241,7 +243,19 @@ static chiron_status upload_gemm(chiron_engine* e, ConvGemmPlan* g, const std::v
   g->Npad = Npad;
   g->K = K;
   chiron_status st;
-  if (e->f16) {
+  if (e->split) {
+    // per 32-element block of a row: 32 hi halves then 32 lo halves (K is a multiple of 32)
+    std::vector<_Float16> h(2 * Wt.size());
+    for (size_t i = 0; i < Wt.size(); ++i) {
+      const _Float16 hi = (_Float16)Wt[i];
+      const size_t blk = i / 32, el = i % 32;
+      h[blk * 64 + el] = hi;
+      h[blk * 64 + 32 + el] = (_Float16)(Wt[i] - (float)hi);
+    }
+    _Float16* d = nullptr;
+    if ((st = dev_upload(e, &d, h))) return st;
+    g->Wt = reinterpret_cast<float*>(d);
+  } else if (e->f16) {
     std::vector<_Float16> h(Wt.size());
     for (size_t i = 0; i < Wt.size(); ++i) h[i] = (_Float16)Wt[i];
     _Float16* d = nullptr;
@@ -257,8 +271,10 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
   const chiron_model_desc& d = e->desc;
   const bool batch = d.bn_mode == CHIRON_BN_BATCH;
   e->bn_batch = batch;
-  if (batch && e->f16) return fail(CHIRON_ERR_INVALID, "bn_mode=batch is implemented for dtype f32 only");
-  if (e->f16) {
+  if (batch && (e->f16 || e->split)) return fail(CHIRON_ERR_INVALID, "bn_mode=batch is implemented for dtype f32 only");
+  if (e->split && d.rnn_kind != CHIRON_RNN_STACK)
+    return fail(CHIRON_ERR_INVALID, "dtype f32-split: only the stacked bidirectional topology (its LSTM inputs start on 32-element blocks)");
+  if (e->f16 || e->split) {
     for (int bi = 0; bi < d.n_blocks; ++bi)
       if (d.blocks[bi].out_channels % GEMM_BN || (d.blocks[bi].in_channels != 1 && d.blocks[bi].in_channels % 64))
         return fail(CHIRON_ERR_INVALID, "dtype f16: block %d has %d -> %d channels; the f16 kernels need multiples of 64 / 128", bi,
@@ -482,7 +498,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   const size_t B = e->maxB, BP = e->BP, L = e->L, T = e->T, H = e->H, K = e->K;
   size_t tmax = 0, cmax = 0;
   for (const BlockPlan& b : e->blocks) {
-    if (!b.lift || e->f16 || e->bn_batch) tmax = std::max<size_t>(tmax, b.t_in);  // f16 / batch-BN materialise the lifted conv2a
+    if (!b.lift || e->f16 || e->split || e->bn_batch) tmax = std::max<size_t>(tmax, b.t_in);  // f16 / batch-BN materialise the lifted conv2a
     tmax = std::max<size_t>(tmax, b.t_out);
     cmax = std::max<size_t>(cmax, b.c);
   }
@@ -494,7 +510,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   if (e->bn_batch && (st = dev_alloc(e, (void**)&s->bn_sums, 2 * 2 * cmax * sizeof(double), true))) return st;
   if ((st = dev_alloc(e, (void**)&s->z, T * BP * 2 * LSTM_ZCOLS * 4, true))) return st;
   for (int i = 0; i < 2; ++i)
-    if ((st = dev_alloc(e, (void**)&s->lasth[i], T * BP * 2 * H * 4, true))) return st;
+    if ((st = dev_alloc(e, (void**)&s->lasth[i], T * BP * (size_t)e->lasth_ld * 4, true))) return st;
   if ((st = dev_alloc(e, (void**)&s->logits, B * T * K * 4, false))) return st;
   if ((st = dev_alloc(e, (void**)&s->labels, B * T, false))) return st;
   if ((st = dev_alloc(e, (void**)&s->count, B * 4, true))) return st;
@@ -531,7 +547,8 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   chiron_weights_size(desc, &want);
   if (want != n_floats) return fail(CHIRON_ERR_INVALID, "weight blob has %zu floats, descriptor needs %zu", n_floats, want);
   if (opts->max_batch < 1 || opts->segment_len < 1) return fail(CHIRON_ERR_INVALID, "max_batch/segment_len must be positive");
-  if (opts->dtype != CHIRON_F32 && opts->dtype != CHIRON_F16) return fail(CHIRON_ERR_INVALID, "dtype %d unknown (0 = f32, 1 = f16)", opts->dtype);
+  if (opts->dtype != CHIRON_F32 && opts->dtype != CHIRON_F16 && opts->dtype != CHIRON_F32_SPLIT)
+    return fail(CHIRON_ERR_INVALID, "dtype %d unknown (0 = f32, 1 = f16, 2 = f32 as hi/lo half pairs)", opts->dtype);
   if (desc->hidden != 100) return fail(CHIRON_ERR_INVALID, "hidden=%d: the recurrence kernel is built for hidden=100 (both shipped models)", desc->hidden);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CHIRON_ERR_DEVICE, "no HIP device visible: libchiron_amd has no CPU fallback");
@@ -548,7 +565,9 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->maxB = opts->max_batch;
   e->BP = roundup(opts->max_batch, 16);
   e->f16 = opts->dtype == CHIRON_F16;
+  e->split = opts->dtype == CHIRON_F32_SPLIT;
   e->kq = e->f16 ? 2 * GEMM_BK : GEMM_BK;
+  e->lasth_ld = e->split ? roundup(2 * desc->hidden, 32) : 2 * desc->hidden;
   {
     const char* ev = getenv("CHIRON_LSTM_ROWS");  // tuning knob; results do not depend on it
     const int r = ev ? atoi(ev) : 4;
@@ -636,6 +655,7 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
 
 // Segments are filled in ELEMENTS; the f16 kernels address in 4-byte units (see GemmParams::f16).
 static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
+  if (e->split) g.f16 = 2;  // same 4-byte element units as fp32; only the content of the 128-byte blocks differs
   if (e->f16) {
     g.f16 = 1;
     for (int i = 0; i < g.nseg; ++i) {
@@ -749,11 +769,11 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.relu = 1;
       g.out = bufB;
       g.ldo = b.c;
-      if (e->f16) {
-        // f16: conv2a of the signal is materialised as halves, conv2b is then an ordinary DMA launch
+      if (e->f16 || e->split) {
+        // f16 / split: conv2a of the signal is materialised, conv2b is then an ordinary DMA launch
         {
           Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_in * b.c, 4.0 * B * b.t_in + 2.0 * B * b.t_in * b.c);
-          launch_lift_f16(sig, b.lift_a, b.lift_b, bufA, (long)B * b.t_in, b.c, s->stream);
+          launch_lift_f16(sig, b.lift_a, b.lift_b, bufA, (long)B * b.t_in, b.c, e->split ? 1 : 0, s->stream);
         }
         for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{bufA, b.c, 0, b.c, cop, b.t_in, b.stride, j - b.left, 0};
         Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 2.0 * B * (b.t_in + b.t_out) * b.c);
@@ -856,9 +876,9 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
       if (l == 0)
         g.seg[0] = GemmSeg{fea, e->C, 0, e->C, Kp, T, 1, 0, 0};
       else if (lp.nproj == 1)
-        g.seg[0] = GemmSeg{prev, 2 * H, 0, 2 * H, Kp, T, 1, 0, 1};
+        g.seg[0] = GemmSeg{prev, e->lasth_ld, 0, 2 * H, Kp, T, 1, 0, 1};
       else
-        g.seg[0] = GemmSeg{prev, 2 * H, pj * H, H, Kp, T, 1, 0, 1};
+        g.seg[0] = GemmSeg{prev, e->lasth_ld, pj * H, H, Kp, T, 1, 0, 1};
       g.out = s->z;
       g.out_mode = 1;
       g.z_cols = LSTM_ZCOLS;
@@ -881,6 +901,8 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.ndir = 2;
     r.rows_per_wg = e->lstm_rows;
     r.f16 = e->f16 ? 1 : 0;
+    r.out_split = e->split ? 1 : 0;
+    r.out_ld = e->lasth_ld;
     {
       Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H, 4.0 * B * T * 2.0 * (zc + H));
       launch_lstm(r, s->stream);
@@ -900,6 +922,8 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
   f.H = H;
   f.K = e->K;
   f.f16 = e->f16 ? 1 : 0;
+  f.split = e->split ? 1 : 0;
+  f.ld = e->lasth_ld;
   {
     Prof pr(e, s, PN_FC, 2.0 * B * T * (2.0 * H + (double)H * e->K), 4.0 * B * T * (2.0 * H + e->K));
     launch_fc(f, s->stream);

@@ -79,7 +79,7 @@ struct RowSplit {
 // Epilogue of the DMA kernel for a tile that lies completely inside N: no per-store bounds checks or branches,
 // one base address per row (the stores use immediate offsets), ReLU as one v_med3 per value, shift already in
 // the accumulators.  ~100 VALU instructions per tile instead of ~350 -- they are all paid in matrix-pipe time.
-template <bool ZOUT, bool RES, bool RELU, bool F16OUT = false>
+template <bool ZOUT, bool RES, bool RELU, int OUTFMT = 0>
 __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
                                                    int li, int kh) {
   if (!ZOUT) {
@@ -95,7 +95,7 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
         sv = p.sig[(long)b * p.L + (long)t * p.res_stride];
       }
       // f16 output: ldo counts 4-byte units, a row holds 2*ldo halves
-      float* orow = p.out + (long)m * p.ldo + (F16OUT ? (n0 + wn * 64 + 4 * kh) / 2 : n0 + wn * 64 + 4 * kh);
+      float* orow = p.out + (long)m * p.ldo + (OUTFMT == 1 ? (n0 + wn * 64 + 4 * kh) / 2 : OUTFMT == 2 ? n0 + wn * 64 : n0 + wn * 64 + 4 * kh);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -112,11 +112,23 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, INFINITY);
           }
-          if (F16OUT) {
+          if (OUTFMT == 1) {
             f16x4 hv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
             *reinterpret_cast<f16x4*>(orow + (ni * 32 + 8 * q) / 2) = hv;
+          } else if (OUTFMT == 2) {
+            // split format: per 32-element block 64 B of hi halves then 64 B of lo halves (x = hi + lo to 2^-22);
+            // this lane's 4 columns are elements e .. e+3 of block ni, e = 8q + 4kh
+            f16x4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              hi[r] = (_Float16)v[r];
+              lo[r] = (_Float16)(v[r] - (float)hi[r]);
+            }
+            _Float16* blk = reinterpret_cast<_Float16*>(orow + ni * 32) + 8 * q + 4 * kh;
+            *reinterpret_cast<f16x4*>(blk) = hi;
+            *reinterpret_cast<f16x4*>(blk + 32) = lo;
           } else {
             *reinterpret_cast<f32x4*>(orow + ni * 32 + 8 * q) = v;
           }
@@ -489,8 +501,12 @@ __device__ __forceinline__ void dma_issue(const DmaSrc& L, float* a_dst, float* 
 
 // CPS = chunks per K-segment (every segment of a launch has the same width), TAIL = the segment's channel
 // count is not a multiple of 32 (its last chunk selects per lane against the K tail).
-template <bool ZOUT, bool RES, int CPS, bool TAIL, bool F16 = false>
+// MODE 0: fp32 operands (v_mfma_f32_32x32x2_f32).  1: IEEE halves (v_mfma_f32_32x32x16_f16).  2: fp32 values carried as
+// exact hi + lo half pairs ("split" format), three f16 MFMAs per product term set: hi*hi + hi*lo + lo*hi, fp32 accumulate.
+template <bool ZOUT, bool RES, int CPS, bool TAIL, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p) {
+  constexpr bool F16 = MODE == 1;
+  constexpr bool SPLIT = MODE == 2;
   __shared__ __attribute__((aligned(16))) float lds[DMA_PAD_F + 4 * DTILE_F + DMA_MAX_N];  // pad A0 A1 B0 B1 shift
   float* const As = lds + DMA_PAD_F;
   float* const Bs = As + 2 * DTILE_F;
@@ -598,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   }
   load_tile(c_id);
   load_segment(p.seg[0], 0);
-  if (TAIL && CPS == 1)
+  if (TAIL && !SPLIT && CPS == 1)
     dma_issue_tail(0, p.seg[0].cin, As + wave * 1024, Bs + wave * 1024);
   else
     dma_issue<0>(L, As + wave * 1024, Bs + wave * 1024);
@@ -607,13 +623,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   int pm0 = 0, pn0 = 0;
   f32x16 acc[2][2];
   const bool relu = p.relu != 0;
-  const int tail_groups = TAIL ? (p.seg[0].cin - (CPS - 1) * GEMM_BK + 7) / 8 : 4;  // 8-column groups of the last chunk
+  // real work of the last chunk of a segment: 8-column groups (fp32 / f16 units), or 16-element k-steps (split)
+  const int tail_groups = TAIL ? (p.seg[0].cin - (CPS - 1) * GEMM_BK + (SPLIT ? 15 : 7)) / (SPLIT ? 16 : 8) : 4;
   auto epilogue = [&](int em0, int en0) {
-    if ((F16 && !ZOUT) || (en0 + GEMM_BN <= p.N && (!ZOUT || 2 * p.z_cols >= p.N))) {  // f16 conv: N % 128 == 0 (launch_gemm)
+    if (((F16 || SPLIT) && !ZOUT) || (en0 + GEMM_BN <= p.N && (!ZOUT || 2 * p.z_cols >= p.N))) {  // f16 / split conv: N % 128 == 0 (launch_gemm)
       if (relu)
-        gemm_epilogue_lean<ZOUT, RES, true, F16 && !ZOUT>(p, acc, em0, en0, wm, wn, li, kh);
+        gemm_epilogue_lean<ZOUT, RES, true, ZOUT ? 0 : MODE>(p, acc, em0, en0, wm, wn, li, kh);
       else
-        gemm_epilogue_lean<ZOUT, RES, false, F16 && !ZOUT>(p, acc, em0, en0, wm, wn, li, kh);
+        gemm_epilogue_lean<ZOUT, RES, false, ZOUT ? 0 : MODE>(p, acc, em0, en0, wm, wn, li, kh);
     } else {
       gemm_epilogue<ZOUT, RES, 0, 16, false>(p, acc, em0, en0, wm, wn, li, kh);
     }
@@ -656,12 +673,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
         auto piece = [&](int q) {
           if (!go) return;
           if (C + 1 < CPS) {
-            if (TAIL && C + 2 == CPS)
+            if (TAIL && !SPLIT && C + 2 == CPS)  // split rows are stored zero padded to whole blocks: nothing to mask
               tail_piece(C + 1, p.seg[sgi].cin, q, a_dst, b_dst);
             else
               dma_piece<(C + 1 < CPS ? C + 1 : 0)>(L, q, a_dst, b_dst);
           } else {
-            if (TAIL && CPS == 1)
+            if (TAIL && !SPLIT && CPS == 1)
               tail_piece(0, p.seg[0].cin, q, a_dst, b_dst);
             else
               dma_piece<0>(L, q, a_dst, b_dst);
@@ -691,6 +708,46 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
         }
         const float* a0 = As + buf * DTILE_F + (wm * 64 + li) * GEMM_BK;
         const float* b0 = Bs + buf * DTILE_F + (wn * 64 + li) * GEMM_BK;
+        if (SPLIT) {
+          // A 128-byte row chunk = 32 elements: slots 0-3 hold the hi halves of elements 0-7 / 8-15 / 16-23 / 24-31,
+          // slots 4-7 the lo halves.  k-step s (16 elements) uses hi slot 2s+kh and lo slot 4+2s+kh, i.e. the fp32
+          // kernel's fragment addresses fslot[s] and fslot[s+2].
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) piece(st * 4 + j);
+            if (TAIL && C + 1 == CPS && st >= tail_groups) continue;  // tail_groups counts 16-element k-steps here
+            f32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              ah[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st]);
+              al[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st + 2]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              bh[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[st]);
+              bl[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[st + 2]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni) {
+                const f16x8 xah = __builtin_bit_cast(f16x8, ah[mi]), xal = __builtin_bit_cast(f16x8, al[mi]);
+                const f16x8 xbh = __builtin_bit_cast(f16x8, bh[ni]), xbl = __builtin_bit_cast(f16x8, bl[ni]);
+                f32x16 c = (FS && C == 0 && st == 0) ? ini[ni] : acc[mi][ni];
+                if (ZOUT) {
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal, xbh, c, 0, 0, 0);   // small terms first
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbh, c, 0, 0, 0);
+                } else {
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbh, xal, c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbl, xah, c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbh, xah, c, 0, 0, 0);
+                }
+                acc[mi][ni] = c;
+              }
+          }
+        } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           // K tail: the last chunk of a segment holds only tail_groups * 8 real columns, the rest multiplies zeros
@@ -729,6 +786,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
             }
           }
         }
+        }
         buf ^= 1;
       };
       chunk(std::integral_constant<int, 0>{});
@@ -760,20 +818,35 @@ static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s
   for (int s = 1; s < p.nseg; ++s)
     if (p.seg[s].kpad != kpad || p.seg[s].cin != cin) return false;
   const bool tail = cin != kpad;
+  if (p.f16 == 2) {
+    // split format: 4-byte units = elements, rows stored zero padded to whole 32-element blocks
+    if (!ZOUT && p.N % GEMM_BN) return false;
+    if (kpad == 256 && !tail) {
+      hipLaunchKernelGGL((gemm_f32_dma_kernel<ZOUT, RES, 8, false, 2>), grid, block, 0, stream, p);
+      return true;
+    }
+    if constexpr (ZOUT) {
+      if (kpad == 224 && tail) {
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 7, true, 2>), grid, block, 0, stream, p);
+        return true;
+      }
+    }
+    return false;
+  }
   if (p.f16) {
     // 4-byte units: 256 halves = 128 units = 4 chunks; LSTM inputs of 200 / 100 halves are padded to 256 / 128 halves
     if (!ZOUT && p.N % GEMM_BN) return false;
     if (kpad == 128 && !tail) {
-      hipLaunchKernelGGL((gemm_f32_dma_kernel<ZOUT, RES, 4, false, true>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((gemm_f32_dma_kernel<ZOUT, RES, 4, false, 1>), grid, block, 0, stream, p);
       return true;
     }
     if constexpr (ZOUT) {
       if (kpad == 128 && tail) {
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4, true, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4, true, 1>), grid, block, 0, stream, p);
         return true;
       }
       if (kpad == 64 && tail) {
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 2, true, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 2, true, 1>), grid, block, 0, stream, p);
         return true;
       }
     }

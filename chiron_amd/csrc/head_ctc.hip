@@ -65,7 +65,13 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
     const int t = (int)(pos - (long)b * p.T);
     f32x4 h = {0.f, 0.f, 0.f, 0.f};
     if (lane < nl) {
-      if (p.f16) {
+      if (p.split) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const int col = 4 * lane;  // 4 consecutive columns never straddle a 32-element block
+        const _Float16* q = reinterpret_cast<const _Float16*>(p.lasth) + (((long)t * p.BP + b) * p.ld + (col >> 5) * 32) * 2 + (col & 31);
+        const f16x4 hi = *reinterpret_cast<const f16x4*>(q), lo = *reinterpret_cast<const f16x4*>(q + 32);
+        h = (f32x4){(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+      } else if (p.f16) {
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
         const f16x4 hh = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.lasth) + ((long)t * p.BP + b) * 2 * H + 4 * lane);
         h = (f32x4){(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]};

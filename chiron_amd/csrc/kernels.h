@@ -92,13 +92,15 @@ struct LstmParams {
   int ndir;              // 2
   int rows_per_wg;       // 4, 8 or 16
   int f16;               // 1: wfrag holds halves in 4x4x4 fragment order, out (lasth) is written as halves; z stays fp32
+  int out_split;         // 1 (fp32 recurrence only): lasth is written in the split hi/lo format of gemm.hip, rows of out_ld elements
+  int out_ld;
 };
 void launch_lstm(const LstmParams& p, hipStream_t stream);
 constexpr int LSTM_KSTEPS16 = 25;  // k-steps of v_mfma_f32_4x4x4_16B_f16 covering K = 100
 
 // relu(sig*a[c] + b[c]) as halves [B*L][C]: res_layer1/conv2a materialised for the f16 path (gemm.hip fuses it into
 // its loader for fp32)
-void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, hipStream_t stream);
+void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int split, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // FC head + CTC (head_ctc.hip)
@@ -112,6 +114,8 @@ struct FcParams {
   float* logits;       // [B][T][K]
   int T, B, BP, H, K;
   int f16;  // lasth holds halves
+  int split;  // lasth in the split hi/lo format, rows of ld elements
+  int ld;
 };
 void launch_fc(const FcParams& p, hipStream_t stream);
 

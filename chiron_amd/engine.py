@@ -34,7 +34,7 @@ class Engine(object):
         if need.value != blob.size:
             raise ValueError("weight blob has %d floats, descriptor needs %d" % (blob.size, need.value))
         opts = _lib.EngineOpts(device_id, max_batch, segment_len, n_slots,
-                               _lib.F32 if dtype == "fp32" else _lib.F16, max_beam)
+                               {"fp32": _lib.F32, "fp16": _lib.F16, "fp32-split": _lib.F32_SPLIT}[dtype], max_beam)
         h = C.c_void_p()
         _lib.check(self._lib.chiron_engine_create(C.byref(desc), blob.ctypes.data_as(C.c_void_p), blob.size,
                                                   C.byref(opts), C.byref(h)))

@@ -350,6 +350,46 @@ def test_batch_statistics_bn_mode(built):
                   max_batch=4, segment_len=400, dtype="fp16")
 
 
+def test_f32_split_dtype_meets_the_fp32_parity_bound(dna):
+    """dtype fp32-split: fp32 values carried as hi + lo half pairs, GEMMs on the f16 matrix cores as
+    hi*hi + hi*lo + lo*hi with fp32 accumulation.  It has to meet the SAME bound against the float64 oracle as the
+    fp32 engine (logits within 1e-4; base strings equal wherever the argmax margin exceeds the error), on ragged
+    batches too, and is deterministic."""
+    from oracle import nn_oracle, ctc_oracle
+    spec, w = dna
+    x, ln = _windows(390 * 40 + 77, 400, 390, seed=61)
+    B = x.shape[0]
+    rng = np.random.RandomState(3)
+    ln = ln.copy()
+    ln[:6] = [0, 1, 399, 200, 37, 400]
+    ln[6:20] = rng.randint(1, 401, size=14)
+    for b in range(B):
+        x[b, ln[b]:] = 0
+    with ca.Engine(spec, w, max_batch=B + 3, segment_len=400, dtype="fp32-split") as es, \
+            ca.Engine(spec, w, max_batch=B + 3, segment_len=400) as e32:
+        sl = ca.seq_len_for_engine(ln, es.ratio)
+        rs = es.infer(x, sl, want_prob=True, want_logits=True)
+        r32 = e32.infer(x, sl, want_prob=True, want_logits=True)
+        assert np.array_equal(es.infer(x, sl, want_logits=True).logits, rs.logits)
+        one = es.infer(x[7:8], sl[7:8], want_logits=True)
+        assert np.array_equal(one.logits[0], rs.logits[7])        # rows are independent of their position / batch
+    ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+    err_s = np.abs(rs.logits.astype(np.float64) - ref).max()
+    err_32 = np.abs(r32.logits.astype(np.float64) - ref).max()
+    assert err_s < TOL, (err_s, err_32)
+    rows = _check_decode(rs, rs.logits, sl, B)
+    orows, _ = ctc_oracle.greedy_decode(ref, sl)
+    srt = np.sort(ref, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    safe = [b for b in range(B) if sl[b] == 0 or margin[b, :sl[b]].min() > 10 * err_s]
+    assert len(safe) >= B // 2
+    for b in safe:
+        assert rows[b] == orows[b]
+    with pytest.raises(_lib.ChironError):                         # MultiRNN inputs do not start on 32-element blocks
+        ca.Engine(ca.rna_default_spec(), ca.synthetic_weights(ca.rna_default_spec(), seed=2), max_batch=4, segment_len=500,
+                  dtype="fp32-split")
+
+
 def test_f16_path_tolerance_vs_f32(dna, rna):
     """BASELINE configs[4]: fp16 conv + LSTM on the f16 MFMA instructions, fp32 accumulation / gates / CTC.
     Tolerance check against the fp32 engine on identical inputs (the fp32 engine is itself within 1e-4 of the

@@ -55,6 +55,10 @@ if __name__ == "__main__":
         run("DNA_default seg400 jump390 b1100 greedy f16", ca.dna_default_spec(), 400, 390, 1100, 0, dtype="fp16")
         run("DNA_default seg400 jump390 b4096 greedy f32", ca.dna_default_spec(), 400, 390, 4096, 0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "split":  # fp32 values as hi/lo half pairs on the f16 matrix cores
+        run("DNA_default seg400 jump390 b1100 greedy fp32-split", ca.dna_default_spec(), 400, 390, 1100, 0, dtype="fp32-split")
+        run("DNA_default seg400 jump390 b1100 greedy fp32", ca.dna_default_spec(), 400, 390, 1100, 0)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "batches":  # kernel time vs batch size (workgroup-count effects)
         for B in [int(v) for v in sys.argv[2:]]:
             run("DNA_default seg400 jump390 b%d greedy" % B, ca.dna_default_spec(), 400, 390, B, 0, steps=4)
