@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--slots", type=int, default=3, help="batches in flight (engine slots / HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu is a self-test of the "
+                    "N>1 code path on a box with one GPU (not a valid measurement)")
+    ap.add_argument("--share-gpu", action="store_true", help="self-test only: every rank uses GPU 0")
     ap.add_argument("--no-f16", action="store_true", help="skip the extra measurements (configs[4]: fp16 batch 4096; fp32-split dtype)")
     args = ap.parse_args()
 
@@ -73,9 +76,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    cdev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # where collectives run
 
     import chiron_amd as ca
     from chiron_amd import assembly
@@ -154,10 +163,10 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        agg = torch.tensor([decoded_bases[0], consensus_bases[0]], dtype=torch.float64, device=dev)
+        agg = torch.tensor([decoded_bases[0], consensus_bases[0]], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         decoded_bases[0], consensus_bases[0] = int(agg[0].item()), int(agg[1].item())
 
@@ -195,7 +204,7 @@ def main():
                        "tflops": round(sum(s["flops"] for s in fam) / (sum(s["total_ms"] for s in fam) * 1e-3) / 1e12, 2),
                        "ms_per_batch": round(sum(s["total_ms"] for s in fam) / 3.0, 3)}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             cpu = cpu_baseline(spec, weights, xb, lb, eng.ratio, args.cpu_windows)
         out = {
             "metric": "kilobases/sec basecalled (DNA_default seg_len=400 batch=1100)",
