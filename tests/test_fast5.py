@@ -66,3 +66,27 @@ def test_extract_writes_signal_files(tmp_path):
 def test_not_hdf5_raises():
     with pytest.raises(fast5.Fast5FormatError):
         fast5.read_fast5(__file__)
+
+
+def test_multi_read_fast5_extract_file_v2(tmp_path):
+    """Multi-read files (extract_sig_ref.py:178-193 extract_file_v2): one record per top-level read group, read_id
+    from the Raw group, reference from that read's own Analyses tree.  The reference ships no multi-read example,
+    so the file comes from tests/h5_writer.py (contiguous and chunked+deflate signal storage)."""
+    from h5_writer import write_multi_read_fast5
+    from chiron_amd import extract
+    rng = np.random.RandomState(4)
+    reads = [("read_%04d" % i, "id-%d-abc" % i, rng.randint(200, 1000, size=n).astype(np.int16),
+              ("@x\nACGT%d\n+\n!!!!!\n" % i) if i != 1 else None) for i, n in enumerate((5000, 1234, 40001))]
+    for chunk in (None, 4096):
+        p = str(tmp_path / ("multi_%s.fast5" % chunk))
+        write_multi_read_fast5(p, reads, chunk=chunk)
+        recs = fast5.read_fast5(p)
+        assert [r["suffix"] for r in recs] == [r[0] for r in reads]
+        for rec, (name, rid, sig, fq) in zip(recs, reads):
+            assert rec["read_id"] == rid and rec["signal"].dtype == np.int16 and np.array_equal(rec["signal"], sig)
+            assert rec["fastq"] == (fq or "")
+    # the extract step writes one .signal per read, named by read id as the reference does for multi-read input
+    out = extract.extract_file(p, mode="dna")
+    assert len(out) == 3
+    rna = extract.extract_file(p, mode="rna")
+    assert np.array_equal(rna[0][1], reads[0][2][::-1]) and rna[0][3] == "id-0-abc" and out[2][2].startswith("@x")
