@@ -885,6 +885,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
       g.z_ndir = lp.nproj == 1 ? 2 : 1;
       g.z_dir0 = lp.nproj == 1 ? 0 : pj;
       g.z_seq_len = s->seq;
+      g.z_f16 = e->f16 ? 1 : 0;
       const double ndir = lp.nproj == 1 ? 2.0 : 1.0;
       Prof pr(e, s, PN_PROJ, 2.0 * B * T * (double)lp.in_w * 4 * H * ndir, 4.0 * B * T * (lp.in_w + ndir * zc));
       ok &= launch(e, g, s->stream);

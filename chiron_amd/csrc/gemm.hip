@@ -40,10 +40,27 @@ struct ZGroup {
     l0 = min(len.x, p.T_out), l1 = min(len.y, p.T_out), l2 = min(len.z, p.T_out), l3 = min(len.w, p.T_out);
   }
   __device__ __forceinline__ void store(const GemmParams& p, int dir, int nl, f32x4 v) const {
-    float* o = p.out + (base + ((unsigned)dir * p.z_cols + nl) * 4);
+    const unsigned col = base + ((unsigned)dir * p.z_cols + nl) * 4;
+    const bool uniform = l0 == l1 && l1 == l2 && l2 == l3;
+    if (p.z_f16) {
+      _Float16* o = reinterpret_cast<_Float16*>(p.out) + col;
+      const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+      if (dir == 0) {
+        *reinterpret_cast<f16x4*>(o + (unsigned)t * per_t) = h;
+      } else if (uniform) {
+        if (t < l0) *reinterpret_cast<f16x4*>(o + (unsigned)(l0 - 1 - t) * per_t) = h;
+      } else {
+        if (t < l0) o[(unsigned)(l0 - 1 - t) * per_t + 0] = h[0];
+        if (t < l1) o[(unsigned)(l1 - 1 - t) * per_t + 1] = h[1];
+        if (t < l2) o[(unsigned)(l2 - 1 - t) * per_t + 2] = h[2];
+        if (t < l3) o[(unsigned)(l3 - 1 - t) * per_t + 3] = h[3];
+      }
+      return;
+    }
+    float* o = p.out + col;
     if (dir == 0) {
       *reinterpret_cast<f32x4*>(o + (unsigned)t * per_t) = v;
-    } else if (l0 == l1 && l1 == l2 && l2 == l3) {
+    } else if (uniform) {
       if (t < l0) *reinterpret_cast<f32x4*>(o + (unsigned)(l0 - 1 - t) * per_t) = v;
     } else {
       if (t < l0) o[(unsigned)(l0 - 1 - t) * per_t + 0] = v[0];

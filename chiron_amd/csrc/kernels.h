@@ -71,6 +71,7 @@ struct GemmParams {
   // ldo are then counted in 4-BYTE UNITS (two halves) so that the loader geometry is the fp32 one; accumulation,
   // shift and the z output stay fp32.
   int f16;
+  int z_f16;  // out_mode 1: z is written as halves (f16 engine: the recurrence converts back; halves the z traffic)
 };
 
 bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel for this shape / dtype

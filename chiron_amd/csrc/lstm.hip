@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
 
   const unsigned outw = p.ndir * p.H;
   const unsigned zstep = (p.BP >> 2) * p.ndir * LSTM_ZCOLS * 4;
-  const unsigned zlane_b = ((g0 * p.ndir + dir) * LSTM_ZCOLS + wave * 64 + lane) * 16;
+  const unsigned zlane_b = ((g0 * p.ndir + dir) * LSTM_ZCOLS + wave * 64 + lane) * 8;   // 4 halves per lane
   const unsigned ostep = p.BP * outw;
   const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
   _Float16* outh = reinterpret_cast<_Float16*>(p.out);
@@ -255,12 +255,13 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
   float c = 0.f, hprev = 0.f;
   int cur = 0;
   for (int s = 0; s < maxlen; ++s) {
-    f32x4 z;
+    // z arrives as halves (gemm.hip ZGroup with z_f16): 8 bytes per lane and step
+    f16x4 zh;
     float touch;
     {
-      const float* zs = p.z + (size_t)s * zstep;
-      const float* zt = p.z + (size_t)min(s + 2, maxlen - 1) * zstep;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z) : "v"(zlane_b), "s"(zs) : "memory");
+      const _Float16* zs = reinterpret_cast<const _Float16*>(p.z) + (size_t)s * zstep;
+      const _Float16* zt = reinterpret_cast<const _Float16*>(p.z) + (size_t)min(s + 2, maxlen - 1) * zstep;
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(zh) : "v"(zlane_b), "s"(zs) : "memory");
       asm volatile("global_load_dword %0, %1, %2" : "=v"(touch) : "v"(zlane_b), "s"(zt) : "memory");
     }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -278,8 +279,8 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
     CHIRON_MF16(16) CHIRON_MF16(17) CHIRON_MF16(18) CHIRON_MF16(19) CHIRON_MF16(20) CHIRON_MF16(21) CHIRON_MF16(22) CHIRON_MF16(23)
     CHIRON_MF16(24)
 #undef CHIRON_MF16
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z), "+v"(touch));
-    const f32x4 v = acc0 + acc1 + z;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh), "+v"(touch));
+    const f32x4 v = acc0 + acc1 + (f32x4){(float)zh[0], (float)zh[1], (float)zh[2], (float)zh[3]};
 #pragma unroll
     for (int r = 0; r < 4; ++r) tw[(r * 16 + (lane & 15)) * 4 + (lane >> 4)] = v[r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
