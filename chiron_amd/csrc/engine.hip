@@ -157,6 +157,7 @@ struct Slot {
   double* bn_sums = nullptr;  // batch-BN mode: two sets of [2][C] sums
   float* z = nullptr;
   float* lasth[2] = {nullptr, nullptr};
+  float* lasth_f32 = nullptr;  // dtype fp32-split: the recurrence writes plain fp32 here, a pass converts it for the next GEMM
   float* logits = nullptr;
   uint8_t* labels = nullptr;
   int32_t* count = nullptr;
@@ -511,6 +512,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   if ((st = dev_alloc(e, (void**)&s->z, T * BP * 2 * LSTM_ZCOLS * 4, true))) return st;
   for (int i = 0; i < 2; ++i)
     if ((st = dev_alloc(e, (void**)&s->lasth[i], T * BP * (size_t)e->lasth_ld * 4, true))) return st;
+  if (e->split && (st = dev_alloc(e, (void**)&s->lasth_f32, T * BP * 2 * H * 4, true))) return st;
   if ((st = dev_alloc(e, (void**)&s->logits, B * T * K * 4, false))) return st;
   if ((st = dev_alloc(e, (void**)&s->labels, B * T, false))) return st;
   if ((st = dev_alloc(e, (void**)&s->count, B * 4, true))) return st;
@@ -894,7 +896,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.z = s->z;
     r.wfrag = lp.wfrag;
     r.seq_len = s->seq;
-    r.out = outbuf;
+    r.out = e->split ? s->lasth_f32 : outbuf;
     r.T = T;
     r.B = B;
     r.BP = BP;
@@ -902,13 +904,19 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.ndir = 2;
     r.rows_per_wg = e->lstm_rows;
     r.f16 = e->f16 ? 1 : 0;
-    r.out_split = e->split ? 1 : 0;
-    r.out_ld = e->lasth_ld;
     {
       Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H, 4.0 * B * T * 2.0 * (zc + H));
       launch_lstm(r, s->stream);
     }
     prev = outbuf;
+    if (e->split) {
+      if (l + 1 < e->lstm.size()) {
+        Prof pr(e, s, PN_REC, 0.0, (4.0 + 4.0) * T * BP * 2.0 * H);
+        launch_split_convert(s->lasth_f32, outbuf, (long)T * BP, 2 * H, e->lasth_ld, s->stream);
+      } else {
+        prev = s->lasth_f32;   // the FC head reads the last layer's fp32 output directly
+      }
+    }
   }
   FcParams f;
   f.lasth = prev;
@@ -923,7 +931,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
   f.H = H;
   f.K = e->K;
   f.f16 = e->f16 ? 1 : 0;
-  f.split = e->split ? 1 : 0;
+  f.split = 0;
   f.ld = e->lasth_ld;
   {
     Prof pr(e, s, PN_FC, 2.0 * B * T * (2.0 * H + (double)H * e->K), 4.0 * B * T * (2.0 * H + e->K));

@@ -93,14 +93,14 @@ struct LstmParams {
   int ndir;              // 2
   int rows_per_wg;       // 4, 8 or 16
   int f16;               // 1: wfrag holds halves in 4x4x4 fragment order, out (lasth) is written as halves; z stays fp32
-  int out_split;         // 1 (fp32 recurrence only): lasth is written in the split hi/lo format of gemm.hip, rows of out_ld elements
-  int out_ld;
 };
 void launch_lstm(const LstmParams& p, hipStream_t stream);
 constexpr int LSTM_KSTEPS16 = 25;  // k-steps of v_mfma_f32_4x4x4_16B_f16 covering K = 100
 
 // relu(sig*a[c] + b[c]) as halves [B*L][C]: res_layer1/conv2a materialised for the f16 path (gemm.hip fuses it into
 // its loader for fp32)
+// fp32 [rows][cols] -> split hi/lo format [rows][ld] (ld a multiple of 32; padding columns are left untouched)
+void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, hipStream_t stream);
 void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int split, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

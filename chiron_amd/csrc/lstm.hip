@@ -44,9 +44,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f), 1.0f);
 }
 
-// OSPLIT: lasth is written in the split hi/lo format of gemm.hip (a template flag: the kernel has no registers to
-// spare for both store paths)
-template <int NG, bool OSPLIT = false>
+template <int NG>
 __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(const LstmParams p) {
   __shared__ __attribute__((aligned(16))) float hbuf[2 * NG * HG];
   __shared__ __attribute__((aligned(16))) float tbuf[LSTM_NW * NG * 256];
@@ -86,9 +84,6 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
   const unsigned zgrp = p.ndir * LSTM_ZCOLS * 4;                 // floats between consecutive row groups
   const unsigned ostep = p.BP * outw;                            // floats between consecutive frames of the output
   const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
-  // split output: half index of this lane's hi half in frame 0 (lo half: +32), halves per frame
-  const unsigned osplit_step = p.BP * p.out_ld * 2;
-  const unsigned osplit_lane = ((g0 * 4 + row) * p.out_ld + (((unsigned)(dir * p.H + unit)) >> 5) * 32) * 2 + ((dir * p.H + unit) & 31);
   float* tw = tbuf + wave * NG * 256;                            // this wave's transpose scratch
   const int hw = ((lane & 15) * 4 + row) * 8 + wave;             // where this lane's cell writes h: blk = unit & 15, q = wave
 
@@ -171,17 +166,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
       if (live) {
         hn[g * HG + hw] = hprev[g];
         const unsigned to = (dir == 0 || !act) ? s : lenr[g] - 1 - s;  // the backward direction walks its frames from the end
-        const float ov = act ? hnew : 0.f;
-        if (OSPLIT) {
-          // split hi/lo format of gemm.hip: 32-element blocks, 32 hi halves then 32 lo halves
-          const unsigned col = dir * p.H + unit;
-          _Float16* o = reinterpret_cast<_Float16*>(p.out) + (to * osplit_step + g * 4 * 2 * p.out_ld + osplit_lane);
-          const _Float16 hi = (_Float16)ov;
-          o[0] = hi;
-          o[32] = (_Float16)(ov - (float)hi);
-        } else {
-          p.out[to * ostep + g * 4 * outw + olane] = ov;
-        }
+        p.out[to * ostep + g * 4 * outw + olane] = act ? hnew : 0.f;
       }
     }
     cur ^= 1;
@@ -193,14 +178,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
     for (int i = tid; i < NG * 4 * p.H; i += 64 * LSTM_NW) {
       const int r = i / p.H;
       const int u = i - r * p.H;
-      if (OSPLIT) {
-        const unsigned col = dir * p.H + u;
-        _Float16* o = reinterpret_cast<_Float16*>(p.out) + ((size_t)((long)s * p.BP + g0 * 4 + r) * p.out_ld + (col >> 5) * 32) * 2 + (col & 31);
-        o[0] = (_Float16)0.f;
-        o[32] = (_Float16)0.f;
-      } else {
-        p.out[((long)s * p.BP + g0 * 4 + r) * outw + dir * p.H + u] = 0.f;
-      }
+      p.out[((long)s * p.BP + g0 * 4 + r) * outw + dir * p.H + u] = 0.f;
     }
   }
 }
@@ -335,6 +313,31 @@ __global__ __launch_bounds__(256) void lift_f16_kernel(const float* __restrict__
   }
 }
 
+// lasth of the fp32 recurrence -> split hi/lo format for the next layer's projection GEMM (dtype fp32-split).  A separate
+// HBM-bound pass: the recurrence has no registers or issue slots to spare for the conversion.
+__global__ __launch_bounds__(256) void split_convert_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long rows, int cols, int ld) {
+  const int c4n = cols / 4;
+  const long total = rows * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c4n;
+    const int c0 = (int)(i - r * c4n) * 4;   // 4 consecutive columns never straddle a 32-element block
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * cols + c0);
+    f16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi[j] = (_Float16)v[j];
+      lo[j] = (_Float16)(v[j] - (float)hi[j]);
+    }
+    _Float16* o = dst + (r * ld + (c0 >> 5) * 32) * 2 + (c0 & 31);
+    *reinterpret_cast<f16x4*>(o) = hi;
+    *reinterpret_cast<f16x4*>(o + 32) = lo;
+  }
+}
+
+void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, hipStream_t stream) {
+  hipLaunchKernelGGL(split_convert_kernel, dim3(256 * 16), dim3(256), 0, stream, src, reinterpret_cast<_Float16*>(dst), rows, cols, ld);
+}
+
 void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int split, hipStream_t stream) {
   if (split)
     hipLaunchKernelGGL(lift_f16_kernel<true>, dim3(256 * 16), dim3(256), 0, stream, sig, a, b, reinterpret_cast<_Float16*>(out), n_pos, C);
@@ -349,8 +352,6 @@ void launch_lstm(const LstmParams& p, hipStream_t stream) {
   const dim3 block(64 * LSTM_NW);
   if (p.f16)
     hipLaunchKernelGGL(lstm16_kernel, dim3(groups * p.ndir), block, 0, stream, p);
-  else if (p.out_split)
-    hipLaunchKernelGGL((lstm_kernel<1, true>), dim3(groups * p.ndir), block, 0, stream, p);
   else if (ng == 1)
     hipLaunchKernelGGL(lstm_kernel<1>, dim3(groups * p.ndir), block, 0, stream, p);
   else if (ng == 2)
