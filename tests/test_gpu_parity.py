@@ -350,6 +350,43 @@ def test_batch_statistics_bn_mode(built):
                   max_batch=4, segment_len=400, dtype="fp16")
 
 
+def test_randomized_shapes_engines_and_slots_against_the_c_oracle(dna, rna):
+    """Many engines in one process (fresh hipMalloc memory is zero, recycled memory is not -- a 256-byte zero page
+    once hid behind that), random batch sizes against random max_batch / slot counts, ragged lengths, both
+    topologies and all three dtypes; fp32 and fp32-split against the C oracle at 1e-4, fp16 against fp32."""
+    from oracle import c_oracle
+    rng = np.random.RandomState(2024)
+    for it in range(10):
+        (spec, w), L, jump = ((dna, 400, 390), (rna, 500, 490))[it % 2]
+        B = int(rng.choice([1, 2, 3, 5, 16, 17, 31, 33, 64, 70]))
+        max_batch = B + int(rng.choice([0, 1, 7, 30]))
+        slots = int(rng.choice([1, 2, 3]))
+        x = ca.synthetic_signal(1, B * L, seed=100 + it)[0].reshape(B, L).copy()
+        ln = rng.randint(0, L + 1, size=B)
+        ln[rng.randint(0, B)] = L
+        for b in range(B):
+            x[b, ln[b]:] = 0
+        T = spec.output_len(L)
+        dtypes = ["fp32"] + (["fp32-split"] if spec.rnn_kind == "stack" else []) + (["fp16"] if it % 3 == 0 else [])
+        outs = {}
+        for dt in dtypes:
+            with ca.Engine(spec, w, max_batch=max_batch, segment_len=L, n_slots=slots, dtype=dt) as eng:
+                sl = ca.seq_len_for_engine(ln, eng.ratio)
+                res = [eng.infer(x, sl, want_prob=True, want_logits=True, slot=s) for s in range(slots)]
+                for r in res[1:]:
+                    assert np.array_equal(r.logits, res[0].logits) and np.array_equal(r.decoded.values, res[0].decoded.values)
+                outs[dt] = res[0]
+                _check_decode(res[0], res[0].logits, sl, B)
+        cref = c_oracle.forward(x, sl, spec.to_dict(), spec.pack(w), T)
+        mask = (np.arange(T)[None, :] < sl[:, None])[..., None]
+        for dt in ("fp32", "fp32-split"):
+            if dt in outs:
+                # frames past seq_len carry no information (the LSTM emits zeros there, the FC bias remains): compare all
+                assert np.abs(outs[dt].logits - cref).max() < TOL, (it, dt, B, max_batch)
+        if "fp16" in outs:
+            assert (np.abs(outs["fp16"].logits - outs["fp32"].logits) * mask).max() < 0.08, (it, B)
+
+
 def test_f32_split_dtype_meets_the_fp32_parity_bound(dna):
     """dtype fp32-split: fp32 values carried as hi + lo half pairs, GEMMs on the f16 matrix cores as
     hi*hi + hi*lo + lo*hi with fp32 accumulation.  It has to meet the SAME bound against the float64 oracle as the
