@@ -102,6 +102,9 @@ def build_parser():
     p.add_argument("--test_number", default=None, type=int, help="Extract test_number reads, default all.")
     p.add_argument("-p", "--preset", default=None, help="Preset evaluation parameters: dna-pre, rna-pre")
     p.add_argument("--device", type=int, default=0, help="HIP device ordinal.")
+    p.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp32-split"],
+                   help="Engine arithmetic: fp32 (parity path), fp16 (f16 MFMA conv + LSTM, fp32 CTC), fp32-split "
+                        "(fp32 values as hi/lo half pairs on the f16 matrix cores).")
     p.add_argument("--synthetic-weights", dest="synthetic_weights", action="store_true",
                    help="Use seeded synthetic weights when the model folder has no checkpoint data.")
     p.set_defaults(func=evaluation)
