@@ -87,6 +87,13 @@ int main(int argc, char** argv) {
     g.B = B; g.BP = BP; g.N = N; g.K = Kp; g.Wt = w2; g.shift = shift; g.z_dirs_total = 2; g.zero_page = zero;
     g.M = T * BP; g.T_out = T; g.m_time_major = 1; g.nseg = 1;
     g.seg[0] = GemmSeg{la, H2, 0, H2, Kp, T, 1, 0, 1};
+    int* seq;
+    hipMalloc(&seq, BP * 4);
+    {
+      std::vector<int> hs(BP, T);
+      hipMemcpy(seq, hs.data(), BP * 4, hipMemcpyHostToDevice);
+    }
+    g.z_seq_len = seq;  // all rows full length: the backward half is stored at step T-1-t
     g.out = z; g.out_mode = 1; g.z_cols = 448; g.z_ndir = 2; g.z_dir0 = 0;
     launch_gemm(g, 0);
     hipDeviceSynchronize();
@@ -100,7 +107,8 @@ int main(int argc, char** argv) {
           double acc = hS[n];
           for (int k = 0; k < H2; ++k) acc += (double)hL[((long)t * BP + b) * H2 + k] * hW2[(long)n * Kp + k];
           const int dir = n / 448, nl = n % 448;
-          const float got = hz[((((long)t * (BP / 4) + (b >> 2)) * 2 + dir) * 448 + nl) * 4 + (b & 3)];
+          const int ts = dir == 0 ? t : T - 1 - t;
+          const float got = hz[((((long)ts * (BP / 4) + (b >> 2)) * 2 + dir) * 448 + nl) * 4 + (b & 3)];
           const double e = fabs(acc - got);
           if (!(e <= worst)) { worst = e; wt_ = t; wb = b; wn = n; }
         }
