@@ -273,8 +273,6 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
   const bool batch = d.bn_mode == CHIRON_BN_BATCH;
   e->bn_batch = batch;
   if (batch && (e->f16 || e->split)) return fail(CHIRON_ERR_INVALID, "bn_mode=batch is implemented for dtype f32 only");
-  if (e->split && d.rnn_kind != CHIRON_RNN_STACK)
-    return fail(CHIRON_ERR_INVALID, "dtype f32-split: only the stacked bidirectional topology (its LSTM inputs start on 32-element blocks)");
   if (e->f16 || e->split) {
     for (int bi = 0; bi < d.n_blocks; ++bi)
       if (d.blocks[bi].out_channels % GEMM_BN || (d.blocks[bi].in_channels != 1 && d.blocks[bi].in_channels % 64))
@@ -569,7 +567,10 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->f16 = opts->dtype == CHIRON_F16;
   e->split = opts->dtype == CHIRON_F32_SPLIT;
   e->kq = e->f16 ? 2 * GEMM_BK : GEMM_BK;
-  e->lasth_ld = e->split ? roundup(2 * desc->hidden, 32) : 2 * desc->hidden;
+  // split: rows hold whole 32-element blocks; MultiRNN reads each direction as its own K-segment, so the backward half
+  // starts on a block boundary (fw at 0, bw at roundup(H, 32))
+  e->lasth_ld = !e->split ? 2 * desc->hidden
+                : desc->rnn_kind == CHIRON_RNN_MULTI ? 2 * roundup(desc->hidden, 32) : roundup(2 * desc->hidden, 32);
   {
     const char* ev = getenv("CHIRON_LSTM_ROWS");  // tuning knob; results do not depend on it
     const int r = ev ? atoi(ev) : 4;
@@ -880,7 +881,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
       else if (lp.nproj == 1)
         g.seg[0] = GemmSeg{prev, e->lasth_ld, 0, 2 * H, Kp, T, 1, 0, 1};
       else
-        g.seg[0] = GemmSeg{prev, e->lasth_ld, pj * H, H, Kp, T, 1, 0, 1};
+        g.seg[0] = GemmSeg{prev, e->lasth_ld, e->split ? pj * roundup(H, 32) : pj * H, H, Kp, T, 1, 0, 1};
       g.out = s->z;
       g.out_mode = 1;
       g.z_cols = LSTM_ZCOLS;
@@ -912,7 +913,8 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     if (e->split) {
       if (l + 1 < e->lstm.size()) {
         Prof pr(e, s, PN_REC, 0.0, (4.0 + 4.0) * T * BP * 2.0 * H);
-        launch_split_convert(s->lasth_f32, outbuf, (long)T * BP, 2 * H, e->lasth_ld, s->stream);
+        const bool multi = e->desc.rnn_kind == CHIRON_RNN_MULTI;
+        launch_split_convert(s->lasth_f32, outbuf, (long)T * BP, 2 * H, e->lasth_ld, multi ? H : 0, multi ? roundup(H, 32) : 0, s->stream);
       } else {
         prev = s->lasth_f32;   // the FC head reads the last layer's fp32 output directly
       }

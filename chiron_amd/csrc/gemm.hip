@@ -847,6 +847,10 @@ static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s
         hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 7, true, 2>), grid, block, 0, stream, p);
         return true;
       }
+      if (kpad == 128 && tail) {
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4, true, 2>), grid, block, 0, stream, p);
+        return true;
+      }
     }
     return false;
   }

@@ -99,8 +99,10 @@ constexpr int LSTM_KSTEPS16 = 25;  // k-steps of v_mfma_f32_4x4x4_16B_f16 coveri
 
 // relu(sig*a[c] + b[c]) as halves [B*L][C]: res_layer1/conv2a materialised for the f16 path (gemm.hip fuses it into
 // its loader for fp32)
-// fp32 [rows][cols] -> split hi/lo format [rows][ld] (ld a multiple of 32; padding columns are left untouched)
-void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, hipStream_t stream);
+// fp32 [rows][cols] -> split hi/lo format [rows][ld] (ld a multiple of 32; padding columns are left untouched).
+// half > 0: the row is two halves of `half` columns (fw | bw) and the second one starts at column half_dst of the
+// destination (a 32-element block boundary), so that each direction can be read as a K-segment of its own.
+void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, int half, int half_dst, hipStream_t stream);
 void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int split, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

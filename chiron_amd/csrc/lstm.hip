@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void lift_f16_kernel(const float* __restrict__
 
 // lasth of the fp32 recurrence -> split hi/lo format for the next layer's projection GEMM (dtype fp32-split).  A separate
 // HBM-bound pass: the recurrence has no registers or issue slots to spare for the conversion.
-__global__ __launch_bounds__(256) void split_convert_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long rows, int cols, int ld) {
+__global__ __launch_bounds__(256) void split_convert_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long rows, int cols, int ld,
+                                                            int half, int half_dst) {
   const int c4n = cols / 4;
   const long total = rows * c4n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -328,14 +329,16 @@ __global__ __launch_bounds__(256) void split_convert_kernel(const float* __restr
       hi[j] = (_Float16)v[j];
       lo[j] = (_Float16)(v[j] - (float)hi[j]);
     }
-    _Float16* o = dst + (r * ld + (c0 >> 5) * 32) * 2 + (c0 & 31);
+    const int cd = (half > 0 && c0 >= half) ? c0 - half + half_dst : c0;   // half is a multiple of 4: a group stays on one side
+    _Float16* o = dst + (r * ld + (cd >> 5) * 32) * 2 + (cd & 31);
     *reinterpret_cast<f16x4*>(o) = hi;
     *reinterpret_cast<f16x4*>(o + 32) = lo;
   }
 }
 
-void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, hipStream_t stream) {
-  hipLaunchKernelGGL(split_convert_kernel, dim3(256 * 16), dim3(256), 0, stream, src, reinterpret_cast<_Float16*>(dst), rows, cols, ld);
+void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, int half, int half_dst, hipStream_t stream) {
+  hipLaunchKernelGGL(split_convert_kernel, dim3(256 * 16), dim3(256), 0, stream, src, reinterpret_cast<_Float16*>(dst), rows, cols, ld, half,
+                     half_dst);
 }
 
 void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int split, hipStream_t stream) {

@@ -97,7 +97,7 @@ chiron_status chiron_weights_size(const chiron_model_desc* desc, size_t* n_float
  *             multiplied on the f16 matrix cores as hi*hi + hi*lo + lo*hi with fp32 accumulation (the f16 MFMA rate is
  *             16x the fp32 one on gfx950); recurrence, gates, z, logits and CTC are the fp32 code.  Opt-in: it meets the
  *             same 1e-4 logits bound against the oracle as CHIRON_F32 (tests) but it is not bit-for-bit fp32 MFMA
- *             arithmetic, so the headline benchmark stays on CHIRON_F32.  STACK topologies, population BN.          */
+ *             arithmetic, so the headline benchmark stays on CHIRON_F32.  Population BN only.          */
 typedef enum { CHIRON_F32 = 0, CHIRON_F16 = 1, CHIRON_F32_SPLIT = 2 } chiron_dtype;
 
 typedef struct {
