@@ -1,17 +1,19 @@
-// Fused conv / LSTM-projection GEMM for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).
+// Fused conv / LSTM-projection GEMM for gfx950 (exact fp32 on v_mfma_f32_32x32x2_f32, 157 TF peak; the f16 and
+// split dtypes run the same kernel on v_mfma_f32_32x32x16_f16).
 //
 // Replaces the tf.nn.conv2d + batch_normalization + relu (+ add) chains of chiron/cnn.py:15-83,
 // :234-262 and the x-part of the LSTMCell MatMul (rnn.py:49-65) of the reference.
 //
-//   block tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves, each wave 64x64 = 2x2 MFMA tiles.
-//   A and B tiles are register-staged into a DOUBLE-BUFFERED LDS image ([rows][36] floats:
-//   conflict-free ds_read_b128 / ds_write_b128), one barrier per K-chunk: while chunk k is on the
-//   matrix pipe, chunk k+1 is written to the other LDS buffer and the global loads of chunk k+2 are
-//   in flight.  K order inside a chunk is permuted (lanes 0-31 take k=8g+j, lanes 32-63 take
-//   k=8g+4+j) so every operand fetch is one ds_read_b128 feeding four MFMAs; A and B use the same
-//   permutation.  The A loader is a small state machine over K-segments (conv taps / fused inputs):
-//   per-row source pointers and validity are computed once per segment, every load is
-//   unconditional from a clamped address and masked afterwards (no divergent branches in the loop).
+//   block tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves, each wave 64x64 = 2x2 MFMA tiles, persistent
+//   workgroups over XCD-aware tile ids.  K order inside a chunk is permuted (lanes 0-31 take k=8g+j, lanes
+//   32-63 take k=8g+4+j) so every operand fetch is one ds_read_b128 feeding four MFMAs; A and B use the same
+//   permutation.  A is a sequence of K-segments (conv taps / fused inputs): per-row source pointers and
+//   validity are computed once per segment.
+//
+//   gemm_f32_dma_kernel  every launch whose A operand is a tensor in HBM: LDS-DMA staging (see below).
+//   gemm_f32_kernel      register-staged ([rows][36] LDS image, masked loads): the lifted first convolution, whose A
+//                        operand relu(sig*a[c]+b[c]) is computed in the loader, and shapes the DMA kernel is not
+//                        instantiated for.
 #include "kernels.h"
 
 #include <type_traits>
