@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libchiron_amd.so")
 MAX_BLOCKS = 8
 CLASSES = 5
 
+ABI_VERSION = 2      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
@@ -30,7 +31,7 @@ class ResBlock(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("n_blocks", C.c_int32), ("blocks", ResBlock * MAX_BLOCKS), ("rnn_kind", C.c_int32),
                 ("rnn_layers", C.c_int32), ("hidden", C.c_int32), ("classes", C.c_int32),
-                ("bn_mode", C.c_int32)]
+                ("bn_mode", C.c_int32), ("stem_k", C.c_int32), ("stem_stride", C.c_int32), ("stem_channels", C.c_int32)]
 
 
 class EngineOpts(C.Structure):

@@ -68,12 +68,14 @@ static chiron_status validate_desc(const chiron_model_desc* d) {
   if (d->n_blocks < 1 || d->n_blocks > CHIRON_MAX_BLOCKS) return fail(CHIRON_ERR_INVALID, "n_blocks %d out of range", d->n_blocks);
   for (int i = 0; i < d->n_blocks; ++i) {
     const chiron_res_block& b = d->blocks[i];
-    const int want_in = i == 0 ? 1 : d->blocks[i - 1].out_channels;
+    const int want_in = i == 0 ? (d->stem_k > 0 ? d->stem_channels : 1) : d->blocks[i - 1].out_channels;
     if (b.in_channels != want_in) return fail(CHIRON_ERR_INVALID, "block %d: in_channels %d, expected %d", i, b.in_channels, want_in);
     if (b.out_channels < 4 || b.out_channels % 4) return fail(CHIRON_ERR_INVALID, "block %d: out_channels must be a multiple of 4", i);
     if (b.k < 1 || b.k > GEMM_MAX_SEG) return fail(CHIRON_ERR_INVALID, "block %d: conv2b width %d unsupported (1..%d)", i, b.k, GEMM_MAX_SEG);
     if (b.stride < 1) return fail(CHIRON_ERR_INVALID, "block %d: stride %d", i, b.stride);
   }
+  if (d->stem_k < 0 || d->stem_k > 64 || (d->stem_k > 0 && (d->stem_stride < 1 || d->stem_channels < 8 || d->stem_channels % 8)))
+    return fail(CHIRON_ERR_INVALID, "stem: k %d stride %d channels %d", d->stem_k, d->stem_stride, d->stem_channels);
   if (d->rnn_kind != CHIRON_RNN_STACK && d->rnn_kind != CHIRON_RNN_MULTI) return fail(CHIRON_ERR_INVALID, "rnn_kind %d", d->rnn_kind);
   if (d->rnn_layers < 1 || d->rnn_layers > 8) return fail(CHIRON_ERR_INVALID, "rnn_layers %d unsupported (1..8)", d->rnn_layers);
   if (d->hidden < 4 || d->hidden > 100 || d->hidden % 4) return fail(CHIRON_ERR_INVALID, "hidden %d unsupported (multiple of 4, <= 100)", d->hidden);
@@ -92,6 +94,7 @@ extern "C" chiron_status chiron_weights_size(const chiron_model_desc* d, size_t*
   if (st) return st;
   if (!n_floats) return fail(CHIRON_ERR_INVALID, "null n_floats");
   size_t n = 0;
+  if (d->stem_k > 0) n += (size_t)d->stem_k * d->stem_channels + 4 * (size_t)d->stem_channels;
   for (int i = 0; i < d->n_blocks; ++i) {
     const chiron_res_block& b = d->blocks[i];
     const size_t ci = b.in_channels, co = b.out_channels;
@@ -197,6 +200,9 @@ struct chiron_engine {
   bool split = false;  // opts.dtype == CHIRON_F32_SPLIT: fp32 values as hi/lo half pairs on the f16 matrix cores (GEMMs only)
   int lasth_ld = 0;    // elements per lasth row (2H; split: rounded up to whole 32-element blocks)
   int kq = GEMM_BK;    // K padding quantum in elements: one LDS chunk = 128 bytes per row (32 floats / 64 halves)
+  // stem (HEAD RNA_model2 / RNA_model3): folded filter [k][C], shift [C]; batch-BN mode: raw filter + scale / offset
+  int stem_k = 0, stem_stride = 1, stem_left = 0, stem_t = 0, stem_c = 0;
+  float *stem_w = nullptr, *stem_shift = nullptr, *stem_scale = nullptr, *stem_offset = nullptr;
   std::vector<BlockPlan> blocks;
   std::vector<LstmPlan> lstm;
   float *fc_w = nullptr, *fc_b = nullptr, *fc_wc = nullptr, *fc_bc = nullptr;
@@ -281,6 +287,32 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
   }
   int t = e->L;
   const float* p = w;
+  if (d.stem_k > 0) {
+    const int k = d.stem_k, co = d.stem_channels;
+    const float* Ws = p;  // [k][1][co]
+    p += (size_t)k * co;
+    std::vector<float> wf((size_t)k * co), sh(co, 0.f);
+    chiron_status st;
+    if (batch) {
+      std::vector<float> sc(p, p + co), of(p + co, p + 2 * co);
+      for (size_t i = 0; i < wf.size(); ++i) wf[i] = Ws[i];
+      if ((st = dev_upload(e, &e->stem_scale, sc))) return st;
+      if ((st = dev_upload(e, &e->stem_offset, of))) return st;
+    } else {
+      const BnFold f = fold_bn(p, p + co, p + 2 * co, p + 3 * co, co);
+      for (int tap = 0; tap < k; ++tap)
+        for (int c = 0; c < co; ++c) wf[(size_t)tap * co + c] = Ws[(size_t)tap * co + c] * f.inv[c];
+      sh = f.sh;
+    }
+    p += 4 * co;
+    if ((st = dev_upload(e, &e->stem_w, wf))) return st;
+    if ((st = dev_upload(e, &e->stem_shift, sh))) return st;
+    e->stem_k = k;
+    e->stem_stride = d.stem_stride;
+    e->stem_c = co;
+    same_pad(t, k, d.stem_stride, &e->stem_t, &e->stem_left);
+    t = e->stem_t;
+  }
   for (int bi = 0; bi < d.n_blocks; ++bi) {
     const chiron_res_block& b = d.blocks[bi];
     BlockPlan bp;
@@ -678,6 +710,15 @@ static bool run_cnn_batch_bn(chiron_engine* e, Slot* s, int B, const float* sig)
   bool ok = true;
   int xi = -1;
   const float* x = nullptr;
+  if (e->stem_k > 0) {
+    const long M0 = (long)B * e->stem_t;
+    launch_stem_conv(sig, e->stem_w, e->stem_shift, s->act[4], B, e->L, e->stem_t, e->stem_k, e->stem_stride, e->stem_left, e->stem_c, 0, 0,
+                     s->stream);
+    launch_bn_stats(s->act[4], M0, e->stem_c, s->bn_sums, s->stream);
+    launch_bn_apply(s->act[4], s->bn_sums, e->stem_scale, e->stem_offset, M0, e->stem_c, 1, nullptr, nullptr, nullptr, nullptr, s->stream);
+    x = s->act[4];
+    xi = 4;
+  }
   for (const BlockPlan& b : e->blocks) {
     float* buf[4];
     for (int i = 0, j = 0; i < 5 && j < 4; ++i)
@@ -752,6 +793,13 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
   bool ok = true;
   float* x = nullptr;  // block input (channels-last [B*T][C])
   int xi = -1;         // which act buffer holds x
+  if (e->stem_k > 0) {
+    Prof pr(e, s, PN_LIFT, 2.0 * B * e->stem_t * (double)e->stem_k * e->stem_c, 4.0 * B * e->L + 4.0 * B * e->stem_t * e->stem_c);
+    launch_stem_conv(sig, e->stem_w, e->stem_shift, s->act[2], B, e->L, e->stem_t, e->stem_k, e->stem_stride, e->stem_left, e->stem_c,
+                     e->f16 ? 1 : e->split ? 2 : 0, 1, s->stream);
+    x = s->act[2];
+    xi = 2;
+  }
   for (const BlockPlan& b : e->blocks) {
     const int cop = roundup(b.c, e->kq);
     // pick two scratch buffers different from x

@@ -336,6 +336,72 @@ __global__ __launch_bounds__(256) void split_convert_kernel(const float* __restr
   }
 }
 
+// Stem convolution on the one-channel signal (HEAD RNA_model2 / RNA_model3): K = k taps only, so it is an elementwise
+// kernel, 8 output channels per thread; BN (population) is folded into w / shift by the engine.
+template <int FMT>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ sig, const float* __restrict__ w, const float* __restrict__ shift,
+                                                        void* __restrict__ outv, int B, int L, int T_out, int k, int stride, int left, int C,
+                                                        int relu) {
+  const int c8 = C / 8;
+  const long total = (long)B * T_out * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pos = i / c8;
+    const int c0 = (int)(i - pos * c8) * 8;
+    const long b = pos / T_out;
+    const int t = (int)(pos - b * T_out);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int tap = 0; tap < k; ++tap) {
+      const int it = t * stride + tap - left;
+      if (it < 0 || it >= L) continue;
+      const float x = sig[b * L + it];
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + tap * C + c0), w1 = *reinterpret_cast<const f32x4*>(w + tap * C + c0 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = fmaf(x, w0[j], acc[j]);
+        acc[4 + j] = fmaf(x, w1[j], acc[4 + j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[j] += shift[c0 + j];
+      if (relu) acc[j] = fmaxf(acc[j], 0.f);
+    }
+    if (FMT == 0) {
+      float* o = reinterpret_cast<float*>(outv) + pos * C + c0;
+      *reinterpret_cast<f32x4*>(o) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+    } else {
+      f16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        hi[j] = (_Float16)acc[j];
+        lo[j] = (_Float16)(acc[j] - (float)hi[j]);
+      }
+      _Float16* oh = reinterpret_cast<_Float16*>(outv);
+      if (FMT == 1) {
+        *reinterpret_cast<f16x8*>(oh + pos * C + c0) = hi;
+      } else {
+        _Float16* o = oh + (pos * C + (c0 >> 5) * 32) * 2 + (c0 & 31);
+        *reinterpret_cast<f16x8*>(o) = hi;
+        *reinterpret_cast<f16x8*>(o + 32) = lo;
+      }
+    }
+  }
+}
+
+void launch_stem_conv(const float* sig, const float* w, const float* shift, void* out, int B, int L, int T_out, int k, int stride, int left,
+                      int C, int fmt, int relu, hipStream_t stream) {
+  const dim3 grid(256 * 16), block(256);
+  if (fmt == 0)
+    hipLaunchKernelGGL(stem_conv_kernel<0>, grid, block, 0, stream, sig, w, shift, out, B, L, T_out, k, stride, left, C, relu);
+  else if (fmt == 1)
+    hipLaunchKernelGGL(stem_conv_kernel<1>, grid, block, 0, stream, sig, w, shift, out, B, L, T_out, k, stride, left, C, relu);
+  else
+    hipLaunchKernelGGL(stem_conv_kernel<2>, grid, block, 0, stream, sig, w, shift, out, B, L, T_out, k, stride, left, C, relu);
+}
+
 void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, int half, int half_dst, hipStream_t stream) {
   hipLaunchKernelGGL(split_convert_kernel, dim3(256 * 16), dim3(256), 0, stream, src, reinterpret_cast<_Float16*>(dst), rows, cols, ld, half,
                      half_dst);

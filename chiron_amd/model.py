@@ -17,10 +17,17 @@ from . import _lib
 
 
 class ModelSpec(object):
-    """blocks: list of dicts {name,in,out,k,stride,i_bn}; rnn_kind 'stack'|'multi'."""
+    """blocks: list of dicts {name,in,out,k,stride,i_bn}; rnn_kind 'stack'|'multi';
+    stem: None or {k, stride, out} -- the conv_layer/conv1 + BN + ReLU in front of the blocks in HEAD's
+    RNA_model2 / RNA_model3 (cnn.py:454-476)."""
 
-    def __init__(self, blocks, rnn_kind="stack", rnn_layers=3, hidden=100, classes=5, bn_mode="population"):
+    STEM_SITE = "conv_layer/conv1"
+
+    def __init__(self, blocks, rnn_kind="stack", rnn_layers=3, hidden=100, classes=5, bn_mode="population", stem=None):
         self.blocks = [dict(b) for b in blocks]
+        self.stem = dict(stem) if stem else None
+        if self.stem and self.blocks[0]["in"] != self.stem["out"]:
+            raise ValueError("first block takes %d channels, the stem produces %d" % (self.blocks[0]["in"], self.stem["out"]))
         self.rnn_kind = rnn_kind
         self.rnn_layers = int(rnn_layers)
         self.hidden = int(hidden)
@@ -52,6 +59,10 @@ class ModelSpec(object):
     def variables(self):
         """Ordered {tf_variable_name: shape} in the blob order of include/chiron_amd.h."""
         v = OrderedDict()
+        if self.stem:
+            v[self.STEM_SITE + "/weights"] = (1, self.stem["k"], 1, self.stem["out"])
+            for nm in ("scale", "offset", "pop_mean", "pop_var"):
+                v[self.STEM_SITE + "_bn/" + nm] = (self.stem["out"],)
         for b in self.blocks:
             n, ci, co, k = b["name"], b["in"], b["out"], b["k"]
             for site, shape, has_bn in ((n + "/branch1/conv1", (1, 1, ci, co), b["i_bn"]),
@@ -87,6 +98,8 @@ class ModelSpec(object):
 
     def output_len(self, segment_len):
         t = segment_len
+        if self.stem:
+            t = int(math.ceil(t / self.stem["stride"]))
         for b in self.blocks:
             t = int(math.ceil(t / b["stride"]))
         return t
@@ -104,13 +117,18 @@ class ModelSpec(object):
         d.hidden = self.hidden
         d.classes = self.classes
         d.bn_mode = _lib.BN_POPULATION if self.bn_mode == "population" else _lib.BN_BATCH
+        if self.stem:
+            d.stem_k, d.stem_stride, d.stem_channels = self.stem["k"], self.stem["stride"], self.stem["out"]
         return d
 
     def to_dict(self):
         """Plain-dict form (what oracle/nn_oracle.py consumes in the tests)."""
-        return {"cnn": [dict(b) for b in self.blocks],
-                "rnn": {"kind": self.rnn_kind, "layers": self.rnn_layers, "hidden": self.hidden},
-                "bn_mode": self.bn_mode, "classes": self.classes}
+        d = {"cnn": [dict(b) for b in self.blocks],
+             "rnn": {"kind": self.rnn_kind, "layers": self.rnn_layers, "hidden": self.hidden},
+             "bn_mode": self.bn_mode, "classes": self.classes}
+        if self.stem:
+            d["stem"] = dict(self.stem)
+        return d
 
 
 def dna_default_spec(bn_mode="population"):
@@ -132,6 +150,18 @@ def rna_default_spec(bn_mode="population"):
     return ModelSpec(blocks, "multi", 3, 100, 5, bn_mode)
 
 
+def rna_head_spec(model="rna_model3", bn_mode="population"):
+    """HEAD's RNA_model2 / RNA_model3 (cnn.py:454-476): a strided stem convolution on the signal
+    (k, stride = 9, 5 / 14, 7) + BN + ReLU, then three stride-1 residual blocks of 256 channels (res_layer1 with BN on
+    its shortcut), MultiRNNCell stacks.  No shipped checkpoint uses it (the shipped RNA_default weights belong to
+    rna_default_spec()); it is what HEAD builds for a newly trained RNA model."""
+    k, stride = {"rna_model2": (9, 5), "rna_model3": (14, 7)}[model]
+    blocks = [{"name": "res_layer1", "in": 256, "out": 256, "k": 3, "stride": 1, "i_bn": True},
+              {"name": "res_layer2", "in": 256, "out": 256, "k": 3, "stride": 1, "i_bn": False},
+              {"name": "res_layer3", "in": 256, "out": 256, "k": 3, "stride": 1, "i_bn": False}]
+    return ModelSpec(blocks, "multi", 3, 100, 5, bn_mode, stem={"k": k, "stride": stride, "out": 256})
+
+
 def read_config(config_file):
     """chiron_model.py:37-48."""
     if config_file is not None:
@@ -151,7 +181,11 @@ def spec_from_config(config, bn_mode="population"):
     if name == "dna_model1":
         spec = dna_default_spec(bn_mode)
     elif name in ("rna_model3", "rna_shipped"):
+        # RNA_default/model.json says rna_model3, but its checkpoint holds the k=13 / stride-5 graph (SURVEY.md section 0
+        # fact 4); with a checkpoint index present spec_from_variables decides, this branch is the index-less default
         spec = rna_default_spec(bn_mode)
+    elif name in ("rna_model2", "rna_model3_head"):
+        spec = rna_head_spec("rna_model2" if name == "rna_model2" else "rna_model3", bn_mode)
     else:
         raise ValueError("CNN model %r has no shipped weights and is not supported" % name)
     spec.rnn_layers = int(rnn["layer_num"])
@@ -166,6 +200,12 @@ def spec_from_variables(shapes, strides=None):
     strides: optional {block_name: stride}; when absent, a k=13 conv2b means
     the shipped RNA block (stride 5, from the .meta Conv2D attrs), else 1."""
     names = set(shapes)
+    stem = None
+    if (ModelSpec.STEM_SITE + "/weights") in names:
+        ws = shapes[ModelSpec.STEM_SITE + "/weights"]
+        k = int(ws[1])
+        # the stride is a graph attribute, not a variable: HEAD pairs k = 9 with 5 and k = 14 with 7 (cnn.py:456, :468)
+        stem = {"k": k, "stride": int((strides or {}).get("conv_layer", {9: 5, 14: 7}.get(k, 1))), "out": int(ws[3])}
     blocks = []
     i = 1
     while ("res_layer%d/branch2/conv2b/weights" % i) in names:
@@ -189,7 +229,7 @@ def spec_from_variables(shapes, strides=None):
         layers += 1
     hidden = int(shapes[pat % 0][0]) // 4
     classes = int(shapes["rnn_fnn_layer/bias_class"][0])
-    return ModelSpec(blocks, kind, layers, hidden, classes, bn_mode)
+    return ModelSpec(blocks, kind, layers, hidden, classes, bn_mode, stem=stem)
 
 
 # ---------------------------------------------------------------------------
@@ -217,6 +257,15 @@ def synthetic_weights(spec, seed=1234, logit_gain=20.0, lstm_gain=3.0):
     # has, so activations neither blow up nor saturate the LSTM gates (constants calibrated once
     # against the float64 oracle on synthetic_signal()).
     m2 = 1.0  # E[x^2] of the block input
+    if spec.stem:
+        k, co = spec.stem["k"], spec.stem["out"]
+        ws = rng.normal(0, math.sqrt(2.0 / (k + co)), (1, k, 1, co)).astype(np.float32)
+        w[spec.STEM_SITE + "/weights"] = ws
+        tap_sum = ws.reshape(k, co).sum(axis=0)
+        # the squiggle is piecewise constant over ~9 samples: neighbouring taps see almost the same level
+        bn(spec.STEM_SITE, co, SIGNAL_MEAN * tap_sum * rng.uniform(0.97, 1.03, co),
+           (SIGNAL_STD * 0.75) ** 2 * (tap_sum ** 2 + (ws.reshape(k, co) ** 2).sum(axis=0)) * rng.uniform(0.8, 1.2, co) + 1e-3)
+        m2 = 0.55
     for b in spec.blocks:
         n, ci, co, k = b["name"], b["in"], b["out"], b["k"]
         xav = lambda fan_in, fan_out, shape: rng.normal(0, math.sqrt(2.0 / (fan_in + fan_out)), shape).astype(np.float32)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CHIRON_ABI_VERSION 1
+#define CHIRON_ABI_VERSION 2
 #define CHIRON_MAX_BLOCKS 8
 #define CHIRON_CLASSES 5 /* A,C,G,T,blank (rnn.py:25 class_n=5) */
 
@@ -68,9 +68,15 @@ typedef struct {
   int32_t hidden;     /* 100                                                  */
   int32_t classes;    /* 5                                                    */
   int32_t bn_mode;    /* chiron_bn_mode                                       */
+  /* Optional stem in front of the residual blocks: HEAD's RNA_model2 / RNA_model3 (cnn.py:454-476) start with
+   *   conv_layer(net, [1, k, 1, C], 'SAME', strides = s) + BN + ReLU  (k, s = 9, 5 / 14, 7; C = 256)
+   * under the variable scope conv_layer/conv1.  stem_k = 0: no stem, blocks[0].in_channels must be 1 (DNA_model1 and
+   * the shipped RNA graph).  With a stem, blocks[0].in_channels = stem_channels.                                 */
+  int32_t stem_k, stem_stride, stem_channels;
 } chiron_model_desc;
 
 /* Weight blob layout (float32, little endian), in this order:
+ *  if stem_k: conv_layer/conv1/weights [k][1][C], conv1_bn scale, offset, pop_mean, pop_var   4 x [C]
  *  for each block b:
  *     branch1/conv1/weights            [1][in][out]        (TF HWIO, H squeezed)
  *     if i_bn: conv1_bn scale, offset, pop_mean, pop_var   4 x [out]

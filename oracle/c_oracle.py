@@ -30,6 +30,8 @@ def load():
 
 
 def _desc(spec):
+    if spec.get("stem"):
+        raise NotImplementedError("the C oracle covers the shipped topologies; stem models are checked with nn_oracle")
     d = [len(spec["cnn"])]
     for b in spec["cnn"]:
         d += [b["in"], b["out"], b["k"], b.get("stride", 1), int(bool(b["i_bn"]))]

@@ -98,6 +98,9 @@ def residual_layer(x, weights, blk, bn_mode):
 def cnn_forward(signal, spec, weights):
     """cnn.py:334-371 getcnnfeature: [B,L] -> [B,T,C]."""
     x = signal[:, :, None]
+    if spec.get("stem"):
+        # HEAD RNA_model2 / RNA_model3 (cnn.py:454-476): conv_layer(net, [1,k,1,C], SAME, strides=s) + BN + ReLU
+        x = conv_layer(x, weights, "conv_layer/conv1", spec["stem"]["stride"], True, True, spec["bn_mode"])
     for blk in spec["cnn"]:
         x = residual_layer(x, weights, blk, spec["bn_mode"])
     return x

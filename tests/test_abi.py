@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import chiron_amd as ca
-from chiron_amd import _lib
+from chiron_amd import _lib, model as model_mod
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == bound, "binding and header disagree: %s" % (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.chiron_abi_version() == 1
+    assert lib.chiron_abi_version() == 2
 
 
 def test_weights_size_and_validation(built):
@@ -86,3 +86,31 @@ def test_chiron_assemble_errors(built):
     counts = np.zeros((4, 1))
     st = lib.chiron_assemble(bases.ctypes.data, off.ctypes.data, 2, None, _lib.KERNAL_STICK, counts.ctypes.data, None, 1, C.byref(n))
     assert st == _lib.ERR_OVERFLOW and n.value == 4
+
+
+def test_stem_topology_contract(built):
+    """HEAD RNA_model2 / RNA_model3 (cnn.py:454-476): stem conv + BN + ReLU in front of three 256-channel blocks.
+    Variable manifest, blob size through the C ABI, topology recovery from variable shapes, frame count."""
+    import ctypes as C
+    lib = _lib.load()
+    for model, (k, stride, T500) in {"rna_model2": (9, 5, 100), "rna_model3": (14, 7, 72)}.items():
+        spec = ca.rna_head_spec(model)
+        v = spec.variables()
+        names = list(v)
+        assert names[0] == "conv_layer/conv1/weights" and v[names[0]] == (1, k, 1, 256)
+        assert names[1:5] == ["conv_layer/conv1_bn/" + n for n in ("scale", "offset", "pop_mean", "pop_var")]
+        assert v["res_layer1/branch1/conv1/weights"] == (1, 1, 256, 256) and "res_layer1/branch1/conv1_bn/scale" in v
+        assert spec.output_len(500) == T500
+        w = ca.synthetic_weights(spec, seed=3)
+        blob = spec.pack(w)
+        n = C.c_size_t()
+        d = spec.to_c()
+        assert (d.stem_k, d.stem_stride, d.stem_channels) == (k, stride, 256)
+        assert lib.chiron_weights_size(C.byref(d), C.byref(n)) == _lib.OK and n.value == blob.size
+        back = model_mod.spec_from_variables({name: a.shape for name, a in w.items()})
+        assert back.stem == spec.stem and back.blocks == spec.blocks and back.rnn_kind == "multi"
+    d = ca.rna_head_spec().to_c()
+    d.stem_channels = 128                                        # does not feed the first block
+    assert lib.chiron_weights_size(C.byref(d), C.byref(n)) == _lib.ERR_INVALID
+    with pytest.raises(ValueError):
+        ca.ModelSpec(ca.dna_default_spec().blocks, stem={"k": 9, "stride": 5, "out": 256})

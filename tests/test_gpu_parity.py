@@ -323,6 +323,42 @@ def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
     monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
 
 
+def test_head_rna_models_with_stem(built):
+    """SURVEY 8 row C5, HEAD variant: RNA_model2 / RNA_model3 (cnn.py:454-476) = strided stem conv (k 9 / 14, stride 5 / 7)
+    + BN + ReLU, three 256-channel blocks (res_layer1 with BN on a 256->256 shortcut), MultiRNN.  fp32 against the
+    float64 oracle at 1e-4 (population and batch BN), ratio 500/72 is not an integer, fp16 / fp32-split against fp32."""
+    from oracle import nn_oracle
+    for model, T in (("rna_model3", 72), ("rna_model2", 100)):
+        spec = ca.rna_head_spec(model)
+        w = ca.synthetic_weights(spec, seed=31)
+        L = 500
+        x, ln = _windows(490 * 9 + 210, L, 490, seed=13)
+        B = x.shape[0]
+        ln = ln.copy()
+        ln[2] = 333
+        with ca.Engine(spec, w, max_batch=B + 2, segment_len=L) as eng:
+            assert eng.T == T and abs(eng.ratio - L / T) < 1e-12
+            sl = ca.seq_len_for_engine(ln, eng.ratio)
+            assert sl.max() <= T
+            res = eng.infer(x, sl, want_prob=True, want_logits=True)
+        ref, ratio = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+        assert abs(ratio - L / T) < 1e-12
+        err = np.abs(res.logits.astype(np.float64) - ref).max()
+        assert err < TOL, (model, err)
+        _check_decode(res, res.logits, sl, B)
+        mask = (np.arange(T)[None, :] < sl[:, None])[..., None]
+        for dt, tol in (("fp32-split", TOL), ("fp16", 0.08)):
+            with ca.Engine(spec, w, max_batch=B + 2, segment_len=L, dtype=dt) as eng:
+                r = eng.infer(x, sl, want_logits=True)
+            assert (np.abs(r.logits - res.logits) * mask).max() < tol, (model, dt)
+    spec = ca.rna_head_spec("rna_model3", bn_mode="batch")
+    w = ca.synthetic_weights(spec, seed=32)
+    with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
+        res = eng.infer(x, sl, want_logits=True)
+    ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+    assert np.abs(res.logits.astype(np.float64) - ref).max() < TOL
+
+
 def test_batch_statistics_bn_mode(built):
     """HEAD's simple_global_bn (cnn.py:166-188): BatchNorm with the moments of THIS batch (biased variance, all
     rows and positions).  The result of a row depends on what else is in the batch, so the comparison uses the
