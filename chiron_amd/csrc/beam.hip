@@ -36,9 +36,12 @@ struct __attribute__((aligned(32))) BeamNode {
 };
 
 __device__ __forceinline__ float log_sum_exp(float a, float b) {  // ctc_loss_util.h LogSumExp
-  if (a == NEG_INF) return b;
-  if (b == NEG_INF) return a;
-  return a > b ? a + log1pf(expf(b - a)) : b + log1pf(expf(a - b));
+  // max + log(1 + exp(min - max)) on the hardware exp2 / log2 (1-2 ulp): the argument of the log lies in (1, 2], so
+  // the absolute error stays at the 1e-7 level of the additions around it.  (The libm-accurate log1pf(expf()) pair was
+  // 300 instructions, two thirds of a frame's work in the register kernel.)
+  const float m = fmaxf(a, b);
+  const float r = m + __logf(1.0f + __expf(fminf(a, b) - m));
+  return (a == NEG_INF) ? b : (b == NEG_INF) ? a : r;
 }
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -323,6 +326,15 @@ __device__ __forceinline__ float wave_min(float v) {
 
 constexpr int B64_FIELDS = 11;
 
+// One wave per workgroup: LDS operations of the wave execute in order, so "synchronising" only has to stop the compiler
+// from reordering around it and drain lgkmcnt.  __syncthreads() would also wait for every outstanding global store
+// (s_waitcnt vmcnt(0)) -- the trie writes of each frame, a few thousand cycles of HBM write latency per frame.
+__device__ __forceinline__ void lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* scratch = reinterpret_cast<int*>(smem);                  // [B64_FIELDS][64] permutation buffer
@@ -418,11 +430,13 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
       }
       int l_node = e_node, l_par = -1, l_lc = e_lc, l_depth = e_depth, l_orig = inb ? lane : -1, l_pi = -1;
 
-      // ---- P2: grow new leaves, event by event, in TF's visiting order (branch-major, label-minor)
-      unsigned long long alive = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
-      unsigned long long odead = 0ull;
+      // ---- P2: grow new leaves, event by event, in TF's visiting order (branch-major, label-minor).
+      // Per lane (= branch) four bit sets over its children c = 0..3 carry the walk's state, so one iteration costs a few
+      // dozen instructions and an event updates only what it touches:
+      //   pend  pairs (lane, c) the walk has not passed yet          act    child c is an alive carried entry
+      //   cdead TF reset child c's old probability already           passed this lane has been entered as a branch
+      //   dead  TF reset THIS lane's old probability (as somebody's child) before the walk reached it
       int nL = nb;
-      int cur_i = -1, cur_c = -1;
       float botv = NEG_INF;
       int boti = 0;
       bool full = nL >= W;
@@ -431,36 +445,35 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         boti = __builtin_ctzll(__ballot(lane < nL && l_tot == botv));
       }
       const bool has_old = inb && e_tot > NEG_INF;
-      while (true) {
-        const bool lane_cur = lane == cur_i;
-        const bool br = has_old && (lane_cur || (lane > cur_i && !((odead >> lane) & 1ull) && (!full || e_tot > botv)));
-        int evc = 4;
-        bool evins = false;
-        float sel_tot = 0.f;
-        int sel_node = -1, sel_co = -1;
+      unsigned pend = has_old ? 0xFu : 0u, act = 0u, cdead = 0u, cfin = 0u, cafter = 0u;
 #pragma unroll
-        for (int c = 3; c >= 0; --c) {
-          const int co = chs[c];
-          const bool active = co >= 0 && ((alive >> co) & 1ull);
-          const float tot = cand[c];
-          const bool cnd = tot > NEG_INF && (!full || tot > botv);
-          // a rejected child that sits in the old beam loses its old probability; that only matters if it
-          // is a branch the walk has not reached yet
-          const bool rst = !cnd && co > lane && !((odead >> co) & 1ull);
-          const bool ev = br && (!lane_cur || c > cur_c) && !active && (cnd || rst);
-          if (ev) {
-            evc = c;
-            evins = cnd;
-            sel_tot = tot;
-            sel_node = e_ch[c];
-            sel_co = co;
-          }
+      for (int c = 0; c < 4; ++c) {
+        if (chs[c] >= 0) act |= 1u << c;         // every carried entry is alive at the start of the frame
+        if (cand[c] > NEG_INF) cfin |= 1u << c;   // finite candidate
+        if (chs[c] > lane) cafter |= 1u << c;     // the child is a branch the walk reaches later
+      }
+      bool passed = false, dead = false;
+      while (true) {
+        const bool br = passed || (!dead && (!full || e_tot > botv));
+        unsigned cnd = cfin;                      // candidates that would enter the leaves now
+        if (full) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (!(cand[c] > botv)) cnd &= ~(1u << c);
         }
-        const unsigned long long evm = __ballot(evc < 4);
+        // a rejected child that sits in the old beam loses its old probability; that only matters if it is a branch the
+        // walk has not reached yet
+        const unsigned rst = ~cnd & cafter & ~cdead;
+        const unsigned ev = br ? (pend & ~act & (cnd | rst)) : 0u;
+        const unsigned long long evm = __ballot(ev != 0u);
         if (evm == 0ull) break;
+        const int evc = __builtin_ctz(ev | 16u);
         const int i = __builtin_ctzll(evm);
         const int c = rli(evc, i);
-        if (rli((int)evins, i)) {
+        const bool ins = (rli((int)cnd, i) >> c) & 1;
+        if (ins) {
+          const float sel_tot = c == 0 ? cand[0] : c == 1 ? cand[1] : c == 2 ? cand[2] : cand[3];   // c is wave-uniform
+          const int sel_node = c == 0 ? e_ch[0] : c == 1 ? e_ch[1] : c == 2 ? e_ch[2] : e_ch[3];
           const float tot = rlf(sel_tot, i);
           const int node = rli(sel_node, i);
           const int pnode = rli(e_node, i);
@@ -469,7 +482,11 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
           if (full) {  // the bottom leaves the search
             slot = boti;
             const int jo = rli(l_orig, slot);
-            if (jo >= 0) alive &= ~(1ull << jo);
+            if (jo >= 0) {  // a carried entry: whoever has it as a child sees it inactive from now on
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (chs[k] == jo) act &= ~(1u << k);
+            }
           } else {
             slot = nL++;
           }
@@ -490,14 +507,23 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
             boti = __builtin_ctzll(__ballot(lane < nL && l_tot == botv));
           }
         } else {
-          odead |= 1ull << rli(sel_co, i);
+          const int sel_co = c == 0 ? chs[0] : c == 1 ? chs[1] : c == 2 ? chs[2] : chs[3];
+          const int co = rli(sel_co, i);
+          if (lane == co) dead = true;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (chs[k] == co) cdead |= 1u << k;
         }
-        cur_i = i;
-        cur_c = c;
+        // the walk is now past (i, c)
+        if (lane < i) pend = 0u;
+        if (lane == i) {
+          pend &= ~((2u << c) - 1u);
+          passed = true;
+        }
       }
 
       // ---- P3: trie bookkeeping, rank the leaves (descending total), permute into rank order
-      if (inb && !((alive >> lane) & 1ull)) slot_of[e_node] = 255;
+      if (inb && l_orig != lane) slot_of[e_node] = 255;   // this lane's carried entry was evicted (its slot holds an inserted child)
       *reinterpret_cast<int4*>(chupd + 4 * lane) = make_int4(-1, -1, -1, -1);
       const bool isleaf = lane < nL;
       const bool inserted = isleaf && l_par >= 0;
@@ -521,8 +547,10 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         f_ch[0] = f_ch[1] = f_ch[2] = f_ch[3] = -1;
       }
       n_nodes += __popcll(fm);
-      __threadfence_block();
-      __syncthreads();
+      // Only a re-inserted node reads the trie back (its children may have been linked by the stores just above), and
+      // only then the wave waits for its own global stores.
+      if (__ballot(inserted && !fresh)) __threadfence_block();
+      lds_sync();
       if (inserted && !fresh) {
         // a node that was in the beam before (possibly evicted earlier in this very frame, after it had
         // spawned children -- hence after the stores above): its children keep their identity
@@ -533,7 +561,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         f_ch[3] = ch.w;
       }
       if (inserted) chupd[4 * l_pi + l_lc] = l_node;
-      __syncthreads();
+      lds_sync();
       if (isleaf && !inserted) {
         const int4 u = *reinterpret_cast<const int4*>(chupd + 4 * lane);
         f_ch[0] = u.x >= 0 ? u.x : f_ch[0];
@@ -560,7 +588,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         scratch[10 * 64 + r] = f_ch[3];
         slot_of[l_node] = (unsigned char)r;
       }
-      __syncthreads();
+      lds_sync();
       nb = nL;
       if (lane < nb) {
         e_tot = __int_as_float(scratch[0 * 64 + lane]);
@@ -575,11 +603,12 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         e_ch[2] = scratch[9 * 64 + lane];
         e_ch[3] = scratch[10 * 64 + lane];
       }
-      __syncthreads();
+      lds_sync();
     }
   }
 
   // ---- TopPaths(1): rank 0 is the leaf with the largest total; labels root -> leaf, no merging
+  __threadfence_block();  // the back-trace reads the trie this wave wrote
   if (lane == 0) {
     int n = e_node;
     uint8_t* out = p.labels + (long)b * T;
