@@ -1051,7 +1051,7 @@ extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, co
   Slot* s = &e->slots[slot];
   HIP_TRY(hipSetDevice(e->opts.device_id));
   if (s->busy) HIP_TRY(hipStreamSynchronize(s->stream));
-  const int B = batch, T = e->T, K = e->K;
+  const int B = batch;
   const float* sig;
   HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
   if (flags & CHIRON_X_ON_DEVICE) {
