@@ -529,7 +529,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   const size_t B = e->maxB, BP = e->BP, L = e->L, T = e->T, H = e->H, K = e->K;
   size_t tmax = 0, cmax = 0;
   for (const BlockPlan& b : e->blocks) {
-    if (!b.lift || e->f16 || e->split || e->bn_batch) tmax = std::max<size_t>(tmax, b.t_in);  // f16 / batch-BN materialise the lifted conv2a
+    tmax = std::max<size_t>(tmax, b.t_in);  // the lifted conv2a is materialised at input resolution
     tmax = std::max<size_t>(tmax, b.t_out);
     cmax = std::max<size_t>(cmax, b.c);
   }
@@ -820,22 +820,14 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.relu = 1;
       g.out = bufB;
       g.ldo = b.c;
-      if (e->f16 || e->split) {
-        // f16 / split: conv2a of the signal is materialised, conv2b is then an ordinary DMA launch
+      {
+        // conv2a of the signal is materialised (one HBM-bound pass), conv2b is then an ordinary DMA launch
         {
-          Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_in * b.c, 4.0 * B * b.t_in + 2.0 * B * b.t_in * b.c);
-          launch_lift_f16(sig, b.lift_a, b.lift_b, bufA, (long)B * b.t_in, b.c, e->split ? 1 : 0, s->stream);
+          Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_in * b.c, 4.0 * B * b.t_in + (e->f16 ? 2.0 : 4.0) * B * b.t_in * b.c);
+          launch_lift(sig, b.lift_a, b.lift_b, bufA, (long)B * b.t_in, b.c, e->f16 ? 1 : e->split ? 2 : 0, s->stream);
         }
         for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{bufA, b.c, 0, b.c, cop, b.t_in, b.stride, j - b.left, 0};
-        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 2.0 * B * (b.t_in + b.t_out) * b.c);
-        ok &= launch(e, g, s->stream);
-      } else {
-        for (int j = 0; j < b.k; ++j) g.seg[j] = GemmSeg{nullptr, 0, 0, b.c, cop, b.t_in, b.stride, j - b.left, 0};
-        g.sig = sig;
-        g.L = e->L;
-        g.lift_a = b.lift_a;
-        g.lift_b = b.lift_b;
-        Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * b.t_out * b.c);
+        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, (e->f16 ? 2.0 : 4.0) * B * (b.t_in + b.t_out) * b.c);
         ok &= launch(e, g, s->stream);
       }
       // conv2c + lifted branch1 + ReLU

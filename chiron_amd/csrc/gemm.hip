@@ -494,23 +494,31 @@ constexpr int DMA_MAX_N = 1024;  // output columns whose shift fits the LDS tabl
 constexpr int DMA_PAD_F = 256;  // floats in front of the tiles: the instruction offset (<= 896 B) is also
                                  // added to the LDS address and is compensated in M0, which must stay >= 0
 
+// The DMA instruction is the RAW-BUFFER form (buffer_load_dwordx4 ... lds): resource descriptor in SGPRs + a 32-bit
+// byte offset per lane.  It costs the issuing wave about half of what global_load_lds_dwordx4 with 64-bit per-lane
+// addresses does (tools/ubench/mfma_shape_vmem.hip: 8 per 4096 MFMA-cycles: +3.6 % vs +10 %), and an offset past
+// num_records reads zeros -- which is exactly what SAME padding, rows past M and K tails need, so no zero page.
+constexpr unsigned DMA_OOB = 0xFFFF0000u;      // >= num_records with any immediate offset added: reads zeros
+constexpr unsigned DMA_RECORDS = 0xFFFE0000u;  // every tensor of the engine is smaller than this many bytes
 struct DmaSrc {
-  const float* aptr[4];  // per piece: source of this lane's 16 bytes for chunk 0 of the current segment
-  const float* bptr[4];
-  bool aok[4];
+  unsigned aoff[4];  // per piece: byte offset (from the segment's tensor) of this lane's 16 bytes for chunk 0, or DMA_OOB
+  unsigned boff[4];  // same for the weights
+  __amdgpu_buffer_rsrc_t ra, rb;
 };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, DMA_RECORDS, 0x00027000);
+}
 
 // Issue one chunk.  The chunk index C inside the segment is a compile-time constant and travels in the
 // instruction's immediate offset, so stepping through a segment costs NO address arithmetic at all: the
-// per-lane pointers stay fixed for the whole segment (rows that read zero padding point at the zero page,
-// where any offset still reads zeros).
+// per-lane offsets stay fixed for the whole segment.
 template <int C>
 __device__ __forceinline__ void dma_piece(const DmaSrc& L, int q, float* a_dst, float* b_dst) {
   if (q < 4)
-    __builtin_amdgcn_global_load_lds((gptr_t)L.aptr[q], (lptr_t)(a_dst + q * 256 - C * GEMM_BK), 16, C * GEMM_BK * 4, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(L.ra, (lptr_t)(a_dst + q * 256 - C * GEMM_BK), 16, L.aoff[q], 0, C * GEMM_BK * 4, 0);
   else
-    __builtin_amdgcn_global_load_lds((gptr_t)L.bptr[q - 4], (lptr_t)(b_dst + (q - 4) * 256 - C * GEMM_BK), 16,
-                                     C * GEMM_BK * 4, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(L.rb, (lptr_t)(b_dst + (q - 4) * 256 - C * GEMM_BK), 16, L.boff[q - 4], 0,
+                                             C * GEMM_BK * 4, 0);
 }
 template <int C>
 __device__ __forceinline__ void dma_issue(const DmaSrc& L, float* a_dst, float* b_dst) {
@@ -574,16 +582,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
 
   // ---- loader: always exactly one chunk ahead of the MFMA loop
   DmaSrc L;
+  L.rb = dma_rsrc(p.Wt);
+  L.ra = L.rb;
   int rb[4], rt[4];
   bool rvalid[4];
-  const float* brow[4];
+  unsigned brow[4];
   auto load_tile = [&](int id) {
     int m0, n0;
     tile_of(id, m0, n0);
     const RowSplit rs(m0, ZOUT ? p.BP : p.T_out);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      brow[j] = p.Wt + (long)(n0 + drow + 8 * j) * p.K + dslot[j];
+      brow[j] = (unsigned)((n0 + drow + 8 * j) * p.K + dslot[j]) * 4u;
       const int m = m0 + drow + 8 * j;
       bool v = m < p.M;
       int b, t;
@@ -599,24 +609,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     }
   };
   auto load_segment = [&](const GemmSeg& sg, int k0) {
+    L.ra = dma_rsrc(sg.src);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int in_t = rt[j] * sg.stride + sg.shift;
       const bool ok = rvalid[j] && in_t >= 0 && in_t < sg.w_in;
       const long row = sg.time_major ? ((long)in_t * p.BP + rb[j]) : ((long)rb[j] * sg.w_in + in_t);
-      L.aok[j] = ok;
-      L.aptr[j] = ok ? sg.src + row * sg.lda + sg.col0 + dslot[j] : p.zero_page + (lane & 7) * 4;
-      L.bptr[j] = brow[j] + k0;
+      L.aoff[j] = ok ? (unsigned)((row * sg.lda + sg.col0 + dslot[j]) * 4) : DMA_OOB;
+      L.boff[j] = brow[j] + (unsigned)k0 * 4u;
     }
   };
   // chunk c of a segment whose channel count is not a multiple of 32: per-lane select against the K tail
   auto tail_piece = [&](int c, int cin, int q, float* a_dst, float* b_dst) {
     if (q < 4) {
-      const bool ok = L.aok[q] && (c * GEMM_BK + dslot[q] < cin);
-      const float* src = ok ? L.aptr[q] + c * GEMM_BK : p.zero_page + (lane & 7) * 4;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + q * 256), 16, 0, 0);
+      const bool ok = L.aoff[q] != DMA_OOB && (c * GEMM_BK + dslot[q] < cin);
+      const unsigned off = ok ? L.aoff[q] + (unsigned)c * GEMM_BK * 4u : DMA_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(L.ra, (lptr_t)(a_dst + q * 256), 16, off, 0, 0, 0);
     } else {
-      __builtin_amdgcn_global_load_lds((gptr_t)(L.bptr[q - 4] + c * GEMM_BK), (lptr_t)(b_dst + (q - 4) * 256), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(L.rb, (lptr_t)(b_dst + (q - 4) * 256), 16, L.boff[q - 4] + (unsigned)c * GEMM_BK * 4u, 0, 0, 0);
     }
   };
   auto dma_issue_tail = [&](int c, int cin, float* a_dst, float* b_dst) {

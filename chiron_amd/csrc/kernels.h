@@ -97,8 +97,7 @@ struct LstmParams {
 void launch_lstm(const LstmParams& p, hipStream_t stream);
 constexpr int LSTM_KSTEPS16 = 25;  // k-steps of v_mfma_f32_4x4x4_16B_f16 covering K = 100
 
-// relu(sig*a[c] + b[c]) as halves [B*L][C]: res_layer1/conv2a materialised for the f16 path (gemm.hip fuses it into
-// its loader for fp32)
+// relu(sig*a[c] + b[c]) [B*L][C]: res_layer1/conv2a materialised in the engine's activation format
 // Stem convolution of HEAD's RNA models (cnn.py:454-476): out[(b,t)][c] = act(sum_tap sig[b][t*stride + tap - left] * w[tap][c]
 // + shift[c]) with TF SAME padding; fmt 0 fp32, 1 halves, 2 split hi/lo; relu = 0 leaves the raw convolution (batch-BN mode).
 void launch_stem_conv(const float* sig, const float* w, const float* shift, void* out, int B, int L, int T_out, int k, int stride, int left,
@@ -107,7 +106,8 @@ void launch_stem_conv(const float* sig, const float* w, const float* shift, void
 // half > 0: the row is two halves of `half` columns (fw | bw) and the second one starts at column half_dst of the
 // destination (a 32-element block boundary), so that each direction can be read as a K-segment of its own.
 void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, int half, int half_dst, hipStream_t stream);
-void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int split, hipStream_t stream);
+void launch_lift(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int fmt /* 0 fp32, 1 halves, 2 split */,
+                 hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // FC head + CTC (head_ctc.hip)

@@ -285,32 +285,52 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
     }
 }
 
-// res_layer1/conv2a materialised for the f16 / split paths: a1[pos][c] = relu(sig[pos]*a[c] + b[c]) as halves, or in the
-// split hi/lo format (per 32 channels: 32 hi halves, 32 lo halves)
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void lift_f16_kernel(const float* __restrict__ sig, const float* __restrict__ a,
-                                                       const float* __restrict__ b, _Float16* __restrict__ out, long n_pos, int C) {
+// res_layer1/conv2a (the 1x1 convolution of the one-channel signal + BN + ReLU) materialised: a1[pos][c] = relu(sig[pos]*a[c]
+// + b[c]).  Folding it into the loader of conv2b (gemm_f32_kernel<LIFT>) saves the 450 MB round trip but forces the
+// register-staged GEMM, which is slower than this pass plus the DMA GEMM.
+template <int FMT>  // 0 fp32, 1 halves, 2 split hi/lo
+__global__ __launch_bounds__(256) void lift_kernel(const float* __restrict__ sig, const float* __restrict__ a, const float* __restrict__ b,
+                                                   void* __restrict__ outv, long n_pos, int C) {
   const int c8 = C / 8;  // 8 channels per thread
   const long total = n_pos * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long pos = i / c8;
     const int c0 = (int)(i - pos * c8) * 8;
     const float x = sig[pos];
-    f16x8 v, lo;
+    float y[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float y = fmaxf(fmaf(x, a[c0 + j], b[c0 + j]), 0.f);
-      v[j] = (_Float16)y;
-      lo[j] = (_Float16)(y - (float)v[j]);
-    }
-    if (SPLIT) {
-      _Float16* o = out + (pos * C + (c0 >> 5) * 32) * 2 + (c0 & 31);
-      *reinterpret_cast<f16x8*>(o) = v;
-      *reinterpret_cast<f16x8*>(o + 32) = lo;
+    for (int j = 0; j < 8; ++j) y[j] = fmaxf(fmaf(x, a[c0 + j], b[c0 + j]), 0.f);
+    if (FMT == 0) {
+      float* o = reinterpret_cast<float*>(outv) + pos * C + c0;
+      *reinterpret_cast<f32x4*>(o) = (f32x4){y[0], y[1], y[2], y[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = (f32x4){y[4], y[5], y[6], y[7]};
     } else {
-      *reinterpret_cast<f16x8*>(out + pos * C + c0) = v;
+      f16x8 v, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = (_Float16)y[j];
+        lo[j] = (_Float16)(y[j] - (float)v[j]);
+      }
+      _Float16* out = reinterpret_cast<_Float16*>(outv);
+      if (FMT == 2) {
+        _Float16* o = out + (pos * C + (c0 >> 5) * 32) * 2 + (c0 & 31);
+        *reinterpret_cast<f16x8*>(o) = v;
+        *reinterpret_cast<f16x8*>(o + 32) = lo;
+      } else {
+        *reinterpret_cast<f16x8*>(out + pos * C + c0) = v;
+      }
     }
   }
+}
+
+void launch_lift(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int fmt, hipStream_t stream) {
+  const dim3 grid(256 * 16), block(256);
+  if (fmt == 0)
+    hipLaunchKernelGGL(lift_kernel<0>, grid, block, 0, stream, sig, a, b, out, n_pos, C);
+  else if (fmt == 1)
+    hipLaunchKernelGGL(lift_kernel<1>, grid, block, 0, stream, sig, a, b, out, n_pos, C);
+  else
+    hipLaunchKernelGGL(lift_kernel<2>, grid, block, 0, stream, sig, a, b, out, n_pos, C);
 }
 
 // lasth of the fp32 recurrence -> split hi/lo format for the next layer's projection GEMM (dtype fp32-split).  A separate
@@ -407,12 +427,6 @@ void launch_split_convert(const float* src, void* dst, long rows, int cols, int 
                      half_dst);
 }
 
-void launch_lift_f16(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int split, hipStream_t stream) {
-  if (split)
-    hipLaunchKernelGGL(lift_f16_kernel<true>, dim3(256 * 16), dim3(256), 0, stream, sig, a, b, reinterpret_cast<_Float16*>(out), n_pos, C);
-  else
-    hipLaunchKernelGGL(lift_f16_kernel<false>, dim3(256 * 16), dim3(256), 0, stream, sig, a, b, reinterpret_cast<_Float16*>(out), n_pos, C);
-}
 
 void launch_lstm(const LstmParams& p, hipStream_t stream) {
   // hidden = 100 is the only size the reference's shipped models use (rnn.py:23 hidden_num=100)

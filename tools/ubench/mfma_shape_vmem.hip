@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int SHAPE, int NV, int ND>
 __global__ __launch_bounds__(512, 1) void k(float* buf, int iters) {
   __shared__ __attribute__((aligned(16))) float lds[8 * 8 * 256 + 4096];
@@ -24,18 +25,25 @@ __global__ __launch_bounds__(512, 1) void k(float* buf, int iters) {
   const float* gp = buf + ((long)blockIdx.x * 512 + threadIdx.x) * 4;
   float* lp = lds + wave * 8 * 256;
   f32x4 sink = {0, 0, 0, 0};
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(buf, 0, 0x7fffffff, 0x00027000);
+  const int voff = (int)(((long)blockIdx.x * 512 + threadIdx.x) * 16);
   __syncthreads();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      if (SHAPE == 32) {
+      if (SHAPE == 32 || SHAPE == 33) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
       } else {
 #pragma unroll
         for (int g = 0; g < 8; ++g) acs[(g + 8 * (i & 1))] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acs[(g + 8 * (i & 1))], 0, 0, 0);
       }
-      if (i < NV) __builtin_amdgcn_global_load_lds((gptr_t)(gp + (i & 7) * 8192), (lptr_t)(lp + (i & 7) * 256), 16, 0, 0);
+      if (i < NV) {
+        if (SHAPE == 33)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lp + (i & 7) * 256), 16, voff + (i & 7) * 32768, 0, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((gptr_t)(gp + (i & 7) * 8192), (lptr_t)(lp + (i & 7) * 256), 16, 0, 0);
+      }
       if (i < ND) asm volatile("ds_read_b128 %0, %1" : "=v"(sink) : "v"((int)(size_t)(lptr_t)(lds + 16384 + lane * 4)));
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
@@ -79,5 +87,7 @@ int main() {
   run<16, 0, 16>(buf);
   run<32, 8, 16>(buf);
   run<16, 8, 16>(buf);
+  run<33, 8, 0>(buf);
+  run<33, 8, 16>(buf);
   return 0;
 }
