@@ -52,9 +52,9 @@ def make_batches(n_batches, rank):
     return (x.reshape(n_batches, BATCH, SEG_LEN), ln.reshape(n_batches, BATCH), tags, win_per_read)
 
 
-# dominant kernel by device time: conv2a / conv2b / conv2c+branch1 of res_layer2,3 (6 launches per batch); template
-# arguments <ZOUT, RES, chunks per K-segment, K tail, f16>
-DOM_KERNEL = "gemm_f32_dma_kernel<false, false, 8, false, false>"
+# dominant kernel by device time: conv2b of res_layer1 and conv2a / conv2b / conv2c+branch1 of res_layer2,3 (7 launches per batch); template
+# arguments <ZOUT, RES, chunks per K-segment, K tail, mode (0 fp32, 1 f16, 2 split)>
+DOM_KERNEL = "gemm_f32_dma_kernel<false, false, 8, false, 0>"
 
 
 def main():
@@ -188,7 +188,7 @@ def main():
                           "gbps": (s["bytes"] / (s["total_ms"] * 1e-3) / 1e9) if s["total_ms"] > 0 else 0.0}
                       for k, s in stats.items()}
         # dominant kernel by time: gemm_f32_dma_kernel<false,false> = conv2a / conv2b / conv2c+branch1 of
-        # res_layer2,3 (6 launches per batch).  The whole GEMM family is summarised in extra.
+        # res_layer1..3 (7 launches per batch).  The whole GEMM family is summarised in extra.
         dom = stats["conv_dma"]
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(DOM_KERNEL)
