@@ -206,7 +206,6 @@ struct chiron_engine {
   std::vector<BlockPlan> blocks;
   std::vector<LstmPlan> lstm;
   float *fc_w = nullptr, *fc_b = nullptr, *fc_wc = nullptr, *fc_bc = nullptr;
-  float* zero_page = nullptr;  // 4 KB of zeros: DMA source for padded rows / K tails (gemm.hip adds immediate offsets < 1 KB)
   std::vector<Slot> slots;
   std::vector<void*> owned;  // device allocations freed on destroy
   bool profiling = false;
@@ -608,8 +607,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     const int r = ev ? atoi(ev) : 4;
     e->lstm_rows = (r == 8 || r == 16) ? r : 4;
   }
-  st = dev_alloc(e, (void**)&e->zero_page, 4096, true);
-  if (st == CHIRON_OK) st = build_plans(e, weights);
+  st = build_plans(e, weights);
   if (st == CHIRON_OK) {
     e->slots.resize(e->opts.n_slots);
     for (Slot& s : e->slots)
@@ -685,7 +683,6 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
   g->Wt = w.Wt;
   g->shift = w.shift;
   g->z_dirs_total = 2;
-  g->zero_page = e->zero_page;
 }
 
 // Segments are filled in ELEMENTS; the f16 kernels address in 4-byte units (see GemmParams::f16).

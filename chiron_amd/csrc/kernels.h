@@ -66,7 +66,6 @@ struct GemmParams {
   int z_dirs_total;  // out_mode 1: directions in the z buffer (2)
   const int32_t* z_seq_len;  // out_mode 1: [BP] sequence lengths; direction 1 is stored time-reversed per row:
                              //   z[s][b][dir 1] = x-projection of frame seq_len[b]-1-s (tf.reverse_sequence folded in)
-  const float* zero_page;  // >= 4 KB of zeros: DMA source of padded rows / K tails
   // f16 = 1 (engine dtype CHIRON_F16): A, Wt and the conv output hold IEEE halves; lda / col0 / cin / kpad / K and
   // ldo are then counted in 4-BYTE UNITS (two halves) so that the loader geometry is the fp32 one; accumulation,
   // shift and the z output stay fp32.

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   {
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.B = B; g.BP = BP; g.N = C; g.K = 3 * C; g.Wt = wt; g.shift = shift; g.z_dirs_total = 2; g.zero_page = zero;
+    g.B = B; g.BP = BP; g.N = C; g.K = 3 * C; g.Wt = wt; g.shift = shift; g.z_dirs_total = 2;
     g.M = (int)M; g.T_out = T; g.nseg = 3;
     for (int j = 0; j < 3; ++j) g.seg[j] = GemmSeg{act, C, 0, C, C, T, 1, j - 1, 0};
     g.relu = 1; g.out = out; g.ldo = C;
@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
     hipMemset(z, 0xff, (long)T * BP * N * 4);
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.B = B; g.BP = BP; g.N = N; g.K = Kp; g.Wt = w2; g.shift = shift; g.z_dirs_total = 2; g.zero_page = zero;
+    g.B = B; g.BP = BP; g.N = N; g.K = Kp; g.Wt = w2; g.shift = shift; g.z_dirs_total = 2;
     g.M = T * BP; g.T_out = T; g.m_time_major = 1; g.nseg = 1;
     g.seg[0] = GemmSeg{la, H2, 0, H2, Kp, T, 1, 0, 1};
     int* seq;

@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     g.Wt = wt;
     g.shift = shift;
     g.z_dirs_total = 2;
-    g.zero_page = zero;
+   
     g.M = (int)M;
     g.T_out = T;
     g.nseg = ntap;
