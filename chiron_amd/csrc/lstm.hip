@@ -166,7 +166,9 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
       if (live) {
         hn[g * HG + hw] = hprev[g];
         const unsigned to = (dir == 0 || !act) ? s : lenr[g] - 1 - s;  // the backward direction walks its frames from the end
-        p.out[to * ostep + g * 4 * outw + olane] = act ? hnew : 0.f;
+        // 32-bit BYTE offset from the scalar base: the store takes the saddr + voffset form, no 64-bit address math
+        const unsigned ob = (to * ostep + g * 4 * outw + olane) * 4u;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + ob) = act ? hnew : 0.f;
       }
     }
     cur ^= 1;
