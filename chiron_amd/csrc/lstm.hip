@@ -94,23 +94,19 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
   // z of step s: ONE 16-byte load per lane and group.  The projection GEMM stores the backward direction by step
   // (frame seq_len-1-s of each row, gemm.hip ZGroup), so neither direction needs per-row addressing here.
   // hipcc sinks an ordinary load down to its first use, where every step would pay a full HBM round trip.  So the
-  // load is issued by hand at the TOP of the step and waited for after the MFMAs, and a 4-byte "touch" of the
-  // slab two steps ahead pulls those lines into L2 early.  (Registers are the limit here -- 128 per lane with two
-  // workgroups per CU, 100 of them hold W_hh -- which rules out a double-buffered 16-byte prefetch.)
+  // load is issued by hand at the TOP of the step and waited for after the MFMAs: with 3-4 waves sharing the SIMD
+  // that is 2-3 us later, enough even for an HBM miss (an extra 4-byte "touch" two steps ahead cost more issue time
+  // than it saved).  Registers are the limit here -- 128 per lane with two workgroups per CU, 100 of them hold
+  // W_hh -- which rules out a double-buffered 16-byte prefetch.
   const unsigned zlane_b = zlane * 4;  // byte offset of this lane inside a step's z slab (scalar base + VGPR offset)
   int cur = 0;
   for (int s = 0; s < maxlen; ++s) {
     f32x4 z[NG];
-    float touch;
     {
       const float* zs = p.z + (size_t)s * zstep;  // wave-uniform
-      const float* zt = p.z + (size_t)min(s + 2, maxlen - 1) * zstep;
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z[g]) : "v"(zlane_b), "s"(zs + g * zgrp) : "memory");
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(touch) : "v"(zlane_b), "s"(zt + g * zgrp) : "memory");
     }
     // ---- acc = h_{s-1} . W_hh : A = h[row][k] broadcast from block k&15, B = this lane's column of W_hh.
     //      One accumulator per group: the 12-cycle dependent-issue latency of the chain is covered by the other
@@ -142,7 +138,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
       }
     }
 #undef CHIRON_MF
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[0]), "+v"(touch));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[0]));
     // ---- gates: transpose (lane = gate*16+unit, reg = row) -> (lane = row*16+unit, reg = gate)
     float* hn = hbuf + (cur ^ 1) * (NG * HG);
 #pragma unroll
@@ -237,12 +233,9 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
   for (int s = 0; s < maxlen; ++s) {
     // z arrives as halves (gemm.hip ZGroup with z_f16): 8 bytes per lane and step
     f16x4 zh;
-    float touch;
     {
       const _Float16* zs = reinterpret_cast<const _Float16*>(p.z) + (size_t)s * zstep;
-      const _Float16* zt = reinterpret_cast<const _Float16*>(p.z) + (size_t)min(s + 2, maxlen - 1) * zstep;
       asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(zh) : "v"(zlane_b), "s"(zs) : "memory");
-      asm volatile("global_load_dword %0, %1, %2" : "=v"(touch) : "v"(zlane_b), "s"(zt) : "memory");
     }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const f16x8 hv = *reinterpret_cast<const f16x8*>(hbuf + cur * HG16 + lane * 8);
@@ -259,7 +252,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
     CHIRON_MF16(16) CHIRON_MF16(17) CHIRON_MF16(18) CHIRON_MF16(19) CHIRON_MF16(20) CHIRON_MF16(21) CHIRON_MF16(22) CHIRON_MF16(23)
     CHIRON_MF16(24)
 #undef CHIRON_MF16
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh), "+v"(touch));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh));
     const f32x4 v = acc0 + acc1 + (f32x4){(float)zh[0], (float)zh[1], (float)zh[2], (float)zh[3]};
 #pragma unroll
     for (int r = 0; r < 4; ++r) tw[(r * 16 + (lane & 15)) * 4 + (lane >> 4)] = v[r];
