@@ -14,7 +14,7 @@
 //
 //   per step and row group:  acc[4 rows] (lane = gate*16 + unit)  <-  h_{t-1} . W_hh      100 MFMAs
 //                            + z_t (x-projection, produced by gemm.hip in exactly this fragment order)
-//                            4x4 transpose through LDS: lane (row, unit) gets i, j, f, o of its cell
+//                            4x4 register transpose (lane swaps): lane (row, unit) gets i, j, f, o of its cell
 //                            c = sig(f)*c + sig(i)*tanh(j);  h = sig(o)*tanh(c)   (forget bias folded in z)
 //   h is exchanged through a double-buffered 2 KB LDS tile per group (A-operand order, see HG), one barrier per step.
 //   Masking: rows with t >= seq_len emit 0 and carry (c,h); the backward direction walks
@@ -44,10 +44,24 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f), 1.0f);
 }
 
+// 4x4 transpose between the register index and lane bits [5:4], in registers: (lane = gate*16 + unit, reg = row) ->
+// (lane = row*16 + unit, reg = gate).  Two gfx950 lane-swap instructions per stage (v_permlane32_swap exchanges the
+// upper 32 lanes of one register with the lower 32 of another, v_permlane16_swap the odd 16-lane rows of one with the
+// even rows of another; checked in tools/ubench/permlane_transpose.hip) instead of a round trip through LDS.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 gate_transpose(f32x4 v) {
+  unsigned a = __float_as_uint(v[0]), b = __float_as_uint(v[1]), c = __float_as_uint(v[2]), d = __float_as_uint(v[3]);
+  u32x2 t;
+  t = __builtin_amdgcn_permlane32_swap(a, c, false, false), a = t[0], c = t[1];
+  t = __builtin_amdgcn_permlane32_swap(b, d, false, false), b = t[0], d = t[1];
+  t = __builtin_amdgcn_permlane16_swap(a, b, false, false), a = t[0], b = t[1];
+  t = __builtin_amdgcn_permlane16_swap(c, d, false, false), c = t[0], d = t[1];
+  return (f32x4){__uint_as_float(a), __uint_as_float(b), __uint_as_float(c), __uint_as_float(d)};
+}
+
 template <int NG>
 __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(const LstmParams p) {
   __shared__ __attribute__((aligned(16))) float hbuf[2 * NG * HG];
-  __shared__ __attribute__((aligned(16))) float tbuf[LSTM_NW * NG * 256];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -84,7 +98,6 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
   const unsigned zgrp = p.ndir * LSTM_ZCOLS * 4;                 // floats between consecutive row groups
   const unsigned ostep = p.BP * outw;                            // floats between consecutive frames of the output
   const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
-  float* tw = tbuf + wave * NG * 256;                            // this wave's transpose scratch
   const int hw = ((lane & 15) * 4 + row) * 8 + wave;             // where this lane's cell writes h: blk = unit & 15, q = wave
 
   float c[NG], hprev[NG];
@@ -143,16 +156,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
     float* hn = hbuf + (cur ^ 1) * (NG * HG);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const f32x4 v = acc[g] + z[g];
-      float* ts = tw + g * 256;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ts[(r * 16 + (lane & 15)) * 4 + (lane >> 4)] = v[r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const f32x4 q = *reinterpret_cast<const f32x4*>(tw + g * 256 + lane * 4);  // i, j, f, o of (row, unit)
+      const f32x4 q = gate_transpose(acc[g] + z[g]);  // i, j, f, o of (row, unit)
       // rows past their length carry (c, h) and emit zeros (dynamic_rnn); whatever their z slot held is discarded
       const bool act = s < lenr[g];
       const float cn = fmaf(fast_sigmoid(q[2]), c[g], fast_sigmoid(q[0]) * fast_tanh(q[1]));
@@ -193,7 +197,6 @@ constexpr int HG16 = 16 * 4 * 8;  // halves per group and buffer
 
 __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParams p) {
   __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * HG16];
-  __shared__ __attribute__((aligned(16))) float tbuf[LSTM_NW * 256];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -224,7 +227,6 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
   const unsigned ostep = p.BP * outw;
   const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
   _Float16* outh = reinterpret_cast<_Float16*>(p.out);
-  float* tw = tbuf + wave * 256;
   // this lane's cell writes h[row][unit]: k-step j = unit/4 = blk + 16q
   const int hw = ((((unit >> 2) & 15) * 4 + row) * 2 + (unit >> 6)) * 4 + (unit & 3);
 
@@ -253,12 +255,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
     CHIRON_MF16(24)
 #undef CHIRON_MF16
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh));
-    const f32x4 v = acc0 + acc1 + (f32x4){(float)zh[0], (float)zh[1], (float)zh[2], (float)zh[3]};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tw[(r * 16 + (lane & 15)) * 4 + (lane >> 4)] = v[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const f32x4 q = *reinterpret_cast<const f32x4*>(tw + lane * 4);  // i, j, f, o of (row, unit)
+    const f32x4 q = gate_transpose(acc0 + acc1 + (f32x4){(float)zh[0], (float)zh[1], (float)zh[2], (float)zh[3]});  // i, j, f, o of (row, unit)
     const bool act = s < lenr;
     const float cn = fmaf(fast_sigmoid(q[2]), c, fast_sigmoid(q[0]) * fast_tanh(q[1]));
     const float hnew = fast_sigmoid(q[3]) * fast_tanh(cn);

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #ifndef GEMM_SRC
@@ -16,12 +17,12 @@
 using namespace chiron;
 
 int main(int argc, char** argv) {
-  const int B = 1100, T = 400, C = 256;
+  const int B = getenv("PROBE_B") ? atoi(getenv("PROBE_B")) : 1100, T = 400, C = 256;
   const long M = (long)B * T;
   float *act, *out, *wt, *shift, *zero;
   hipMalloc(&act, M * C * 4);
   hipMalloc(&out, M * C * 4);
-  hipMalloc(&wt, 768 * 256 * 4);
+  hipMalloc(&wt, 2048 * 256 * 4);
   hipMalloc(&shift, 256 * 4);
   hipMalloc(&zero, 4096);
   hipMemset(zero, 0, 4096);
@@ -32,14 +33,14 @@ int main(int argc, char** argv) {
     v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
   }
   hipMemcpy(act, h.data(), M * C * 4, hipMemcpyHostToDevice);
-  hipMemcpy(wt, h.data(), 768 * 256 * 4, hipMemcpyHostToDevice);
+  hipMemcpy(wt, h.data(), 2048 * 256 * 4, hipMemcpyHostToDevice);
   hipMemcpy(shift, h.data(), 256 * 4, hipMemcpyHostToDevice);
 
-  for (int ntap = 1; ntap <= 3; ntap += 2) {
+  for (int ntap = 1; ntap <= (getenv("PROBE_MAXTAP") ? atoi(getenv("PROBE_MAXTAP")) : 3); ntap += (getenv("PROBE_MAXTAP") ? 1 : 2)) {
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.B = B;
-    g.BP = 1104;
+    g.BP = (B + 3) / 4 * 4;
     g.N = C;
     g.K = ntap * C;
     g.Wt = wt;
