@@ -437,10 +437,9 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
   e->T = t;
   e->C = d.blocks[d.n_blocks - 1].out_channels;
 
-  // ---- LSTM layers.  z column n of a direction: wave = n/64, gate = (n%64)/16, unit = 16*wave + n%16
-  // (the accumulator-fragment order of lstm.hip).
+  // ---- LSTM layers.  z column n of a direction: gate = n / H, unit = n % H (the order of the TF kernel's columns).
   const int H = d.hidden;
-  const int zc = LSTM_ZCOLS;
+  const int zc = 4 * H;
   for (int l = 0; l < d.rnn_layers; ++l) {
     LstmPlan lp;
     lp.in_w = lstm_in_width(&d, l);
@@ -464,8 +463,7 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       for (int n = 0; n < N; ++n) {
         const int dir = split ? pj : n / zc;
         const int nl = n % zc;
-        const int g = (nl % 64) / 16, unit = 16 * (nl / 64) + nl % 16;
-        if (unit >= H) continue;
+        const int g = nl / H, unit = nl % H;
         for (int k = 0; k < lp.in_w; ++k) Wt[(size_t)n * Kp + k] = kern[dir][(size_t)k * 4 * H + g * H + unit];
         // forget_bias = 1.0 (TF LSTMCell default; Add(+1.0) const in the .meta while-body) folded here
         sh[n] = bias[dir][g * H + unit] + (g == 2 ? 1.0f : 0.0f);
@@ -538,7 +536,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   for (int i = 0; i < (e->bn_batch ? 5 : 3); ++i)
     if ((st = dev_alloc(e, (void**)&s->act[i], B * tmax * cmax * (e->f16 ? 2 : 4), false))) return st;
   if (e->bn_batch && (st = dev_alloc(e, (void**)&s->bn_sums, 2 * 2 * cmax * sizeof(double), true))) return st;
-  if ((st = dev_alloc(e, (void**)&s->z, T * BP * 2 * LSTM_ZCOLS * 4, true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->z, (size_t)T * BP * 2 * 4 * H * 4, true))) return st;
   for (int i = 0; i < 2; ++i)
     if ((st = dev_alloc(e, (void**)&s->lasth[i], T * BP * (size_t)e->lasth_ld * 4, true))) return st;
   if (e->split && (st = dev_alloc(e, (void**)&s->lasth_f32, T * BP * 2 * H * 4, true))) return st;
@@ -900,7 +898,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
   bool ok = true;
   const float* fea = s->sig_used;
   const int T = e->T, H = e->H, BP = e->BP;
-  const int zc = LSTM_ZCOLS;
+  const int zc = 4 * H;
   const float* prev = nullptr;
   for (size_t l = 0; l < e->lstm.size(); ++l) {
     const LstmPlan& lp = e->lstm[l];
@@ -921,7 +919,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
         g.seg[0] = GemmSeg{prev, e->lasth_ld, e->split ? pj * roundup(H, 32) : pj * H, H, Kp, T, 1, 0, 1};
       g.out = s->z;
       g.out_mode = 1;
-      g.z_cols = LSTM_ZCOLS;
+      g.z_cols = zc;
       g.z_ndir = lp.nproj == 1 ? 2 : 1;
       g.z_dir0 = lp.nproj == 1 ? 0 : pj;
       g.z_seq_len = s->seq;

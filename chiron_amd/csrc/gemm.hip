@@ -181,6 +181,28 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
   }
 }
 
+// Epilogue of a NARROW projection tile (at most 32 live columns: the last N tile of the 800- or 400-column LSTM
+// projection).  The four waves split the 128 rows instead of the columns: wave w owns rows 32w .. 32w+31 and ONE
+// 32x32 accumulator, so the tile costs a quarter of the MFMAs of a full one instead of all of them.
+__device__ __forceinline__ void gemm_epilogue_narrow(const GemmParams& p, const f32x16& acc, int m0, int n0, int wave, int li, int kh) {
+  const int n = n0 + li;
+  if (n >= p.N) return;
+  const int dir = p.z_dir0 + n / p.z_cols;
+  const int nl = n % p.z_cols;
+  const RowSplit rs(m0, p.BP);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int dm = wave * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows: one 4-row group of lstm.hip
+    if (m0 + dm >= p.M) continue;
+    int t, b;
+    rs.split(dm, t, b);
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[4 * q + r];
+    ZGroup(p, t, b).store(p, dir, nl, v);
+  }
+}
+
 // Stores LO <= idx < HI of the 16 16-byte stores a lane owns (idx = (outer*2 + inner)*4 + q): the DMA kernel
 // spreads one tile's stores over the first chunks of the next tile.
 template <bool ZOUT, bool RES, int LO = 0, int HI = 16, bool ADD_SHIFT = true>
@@ -654,7 +676,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   const bool relu = p.relu != 0;
   // real work of the last chunk of a segment: 8-column groups (fp32 / f16 units), or 16-element k-steps (split)
   const int tail_groups = TAIL ? (p.seg[0].cin - (CPS - 1) * GEMM_BK + (SPLIT ? 15 : 7)) / (SPLIT ? 16 : 8) : 4;
+  bool pnarrow = false;
   auto epilogue = [&](int em0, int en0) {
+    if (ZOUT && pnarrow) {
+      gemm_epilogue_narrow(p, acc[0][0], em0, en0, wave, li, kh);
+      return;
+    }
     if (((F16 || SPLIT) && !ZOUT) || (en0 + GEMM_BN <= p.N && (!ZOUT || 2 * p.z_cols >= p.N))) {  // f16 / split conv: N % 128 == 0 (launch_gemm)
       if (relu)
         gemm_epilogue_lean<ZOUT, RES, true, ZOUT ? 0 : MODE>(p, acc, em0, en0, wm, wn, li, kh);
@@ -674,6 +701,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     tile_of(c_id, m0, n0);
     const int n_id = next_valid(c_id);
     int k0 = 0;
+    // last N tile of an LSTM projection with <= 32 live columns: the waves split the rows (gemm_epilogue_narrow)
+    const bool narrow = ZOUT && p.N - n0 <= 32;
 
     auto segment = [&](auto first_tag, int sgi) {
       constexpr bool FS = decltype(first_tag)::value;  // first K-segment of the tile
@@ -719,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             if (ZOUT) {
-              const float sh = shl[n0 + wn * 64 + ni * 32 + li];
+              const float sh = shl[n0 + (narrow ? 0 : wn * 64) + ni * 32 + li];
 #pragma unroll
               for (int r = 0; r < 16; ++r) ini[ni][r] = sh;
             } else {
@@ -735,87 +764,101 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
           // vmcnt(0) then only ever waits for DMA issued a whole chunk earlier, never for fresh stores.
           if (have_prev) epilogue(pm0, pn0);
         }
-        const float* a0 = As + buf * DTILE_F + (wm * 64 + li) * GEMM_BK;
-        const float* b0 = Bs + buf * DTILE_F + (wn * 64 + li) * GEMM_BK;
-        if (SPLIT) {
-          // A 128-byte row chunk = 32 elements: slots 0-3 hold the hi halves of elements 0-7 / 8-15 / 16-23 / 24-31,
-          // slots 4-7 the lo halves.  k-step s (16 elements) uses hi slot 2s+kh and lo slot 4+2s+kh, i.e. the fp32
-          // kernel's fragment addresses fslot[s] and fslot[s+2].
+        auto mma = [&](auto narrow_tag) {
+          constexpr bool NW = decltype(narrow_tag)::value;  // narrow tile: wave w -> rows 32w.., columns 0..31
+          constexpr int NMI = NW ? 1 : 2, NNI = NW ? 1 : 2;
+          const float* a0 = As + buf * DTILE_F + ((NW ? wave * 32 : wm * 64) + li) * GEMM_BK;
+          const float* b0 = Bs + buf * DTILE_F + ((NW ? 0 : wn * 64) + li) * GEMM_BK;
+          if (SPLIT) {
+            // A 128-byte row chunk = 32 elements: slots 0-3 hold the hi halves of elements 0-7 / 8-15 / 16-23 / 24-31,
+            // slots 4-7 the lo halves.  k-step s (16 elements) uses hi slot 2s+kh and lo slot 4+2s+kh, i.e. the fp32
+            // kernel's fragment addresses fslot[s] and fslot[s+2].
 #pragma unroll
-          for (int st = 0; st < 2; ++st) {
+            for (int st = 0; st < 2; ++st) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) piece(st * 4 + j);
-            if (TAIL && C + 1 == CPS && st >= tail_groups) continue;  // tail_groups counts 16-element k-steps here
-            f32x4 ah[2], al[2], bh[2], bl[2];
+              for (int j = 0; j < 4; ++j) piece(st * 4 + j);
+              if (TAIL && C + 1 == CPS && st >= tail_groups) continue;  // tail_groups counts 16-element k-steps here
+              f32x4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-              ah[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st]);
-              al[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st + 2]);
-            }
+              for (int mi = 0; mi < NMI; ++mi) {
+                ah[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st]);
+                al[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st + 2]);
+              }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              bh[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[st]);
-              bl[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[st + 2]);
-            }
+              for (int ni = 0; ni < NNI; ++ni) {
+                bh[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[st]);
+                bl[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[st + 2]);
+              }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+              for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
-              for (int ni = 0; ni < 2; ++ni) {
-                const f16x8 xah = __builtin_bit_cast(f16x8, ah[mi]), xal = __builtin_bit_cast(f16x8, al[mi]);
-                const f16x8 xbh = __builtin_bit_cast(f16x8, bh[ni]), xbl = __builtin_bit_cast(f16x8, bl[ni]);
-                f32x16 c = (FS && C == 0 && st == 0) ? ini[ni] : acc[mi][ni];
-                if (ZOUT) {
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal, xbh, c, 0, 0, 0);   // small terms first
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbh, c, 0, 0, 0);
-                } else {
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbh, xal, c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbl, xah, c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbh, xah, c, 0, 0, 0);
+                for (int ni = 0; ni < NNI; ++ni) {
+                  const f16x8 xah = __builtin_bit_cast(f16x8, ah[mi]), xal = __builtin_bit_cast(f16x8, al[mi]);
+                  const f16x8 xbh = __builtin_bit_cast(f16x8, bh[ni]), xbl = __builtin_bit_cast(f16x8, bl[ni]);
+                  f32x16 c = (FS && C == 0 && st == 0) ? ini[ni] : acc[mi][ni];
+                  if (ZOUT) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal, xbh, c, 0, 0, 0);   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbh, c, 0, 0, 0);
+                  } else {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbh, xal, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbl, xah, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xbh, xah, c, 0, 0, 0);
+                  }
+                  acc[mi][ni] = c;
                 }
-                acc[mi][ni] = c;
-              }
-          }
-        } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          // K tail: the last chunk of a segment holds only tail_groups * 8 real columns, the rest multiplies zeros
-          if (TAIL && C + 1 == CPS && g >= 2 && g >= tail_groups) continue;
-          f32x4 a[2], b[2];
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[g]);
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[g]);
-          if (F16) {
-            // 16 bytes = the 8 halves of one k-step of v_mfma_f32_32x32x16_f16 (lanes 0-31: k 0-7, lanes 32-63: k 8-15)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (g < 2) piece(g * 4 + j);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni) {
-                const f32x16 c = (FS && C == 0 && g == 0) ? ini[ni] : acc[mi][ni];
-                const f16x8 ah = __builtin_bit_cast(f16x8, a[mi]), bh = __builtin_bit_cast(f16x8, b[ni]);
-                acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0)
-                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, c, 0, 0, 0);
-              }
+            }
           } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (g < 2) piece(g * 4 + j);
+          for (int g = 0; g < 4; ++g) {
+            // K tail: the last chunk of a segment holds only tail_groups * 8 real columns, the rest multiplies zeros
+            if (TAIL && C + 1 == CPS && g >= tail_groups) {  // nothing but zeros to multiply: only the DMA pieces this group carries
+              if (g < 2) {
 #pragma unroll
-              for (int mi = 0; mi < 2; ++mi)
+                for (int j = 0; j < 4; ++j) piece(g * 4 + j);
+              }
+              continue;
+            }
+            f32x4 a[2], b[2];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                  const f32x16 c = (FS && C == 0 && g == 0 && j == 0) ? ini[ni] : acc[mi][ni];
-                  acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], c, 0, 0, 0)
-                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][j], a[mi][j], c, 0, 0, 0);
+            for (int mi = 0; mi < NMI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[g]);
+#pragma unroll
+            for (int ni = 0; ni < NNI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[g]);
+            if (F16) {
+              // 16 bytes = the 8 halves of one k-step of v_mfma_f32_32x32x16_f16 (lanes 0-31: k 0-7, lanes 32-63: k 8-15)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (g < 2) piece(g * 4 + j);
+#pragma unroll
+              for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NNI; ++ni) {
+                  const f32x16 c = (FS && C == 0 && g == 0) ? ini[ni] : acc[mi][ni];
+                  const f16x8 ah = __builtin_bit_cast(f16x8, a[mi]), bh = __builtin_bit_cast(f16x8, b[ni]);
+                  acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, c, 0, 0, 0);
                 }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (g < 2) piece(g * 4 + j);
+#pragma unroll
+                for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+                  for (int ni = 0; ni < NNI; ++ni) {
+                    const f32x16 c = (FS && C == 0 && g == 0 && j == 0) ? ini[ni] : acc[mi][ni];
+                    acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], c, 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][j], a[mi][j], c, 0, 0, 0);
+                  }
+              }
             }
           }
-        }
-        }
+          }
+        };
+        if (ZOUT && narrow)
+          mma(std::true_type{});
+        else
+          mma(std::false_type{});
         buf ^= 1;
       };
       chunk(std::integral_constant<int, 0>{});
@@ -831,6 +874,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     for (int sgi = 1; sgi < nseg; ++sgi) segment(std::false_type{}, sgi);
 
     have_prev = true;
+    pnarrow = narrow;
     pm0 = m0;
     pn0 = n0;
     c_id = n_id;

@@ -60,7 +60,7 @@ struct GemmParams {
   float* out;
   int ldo;         // row stride (out_mode 0)
   int out_mode;    // 0: out[m*ldo + n];  1: LSTM z fragment layout (see lstm.hip)
-  int z_cols;      // out_mode 1: z columns per direction (LSTM_ZCOLS)
+  int z_cols;      // out_mode 1: z columns per direction (4*H, TF gate-major order i, j, f, o)
   int z_ndir;      // out_mode 1: directions interleaved in N (N = z_ndir * z_cols)
   int z_dir0;      // out_mode 1: first direction index written by this launch
   int z_dirs_total;  // out_mode 1: directions in the z buffer (2)
@@ -80,10 +80,9 @@ bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel 
 // ---------------------------------------------------------------------------------------------
 constexpr int LSTM_K = 100;      // hidden size the kernel is built for (rnn.py:23 hidden_num=100)
 constexpr int LSTM_NW = 7;       // waves per workgroup; wave w owns hidden units [16w, 16w+16)
-constexpr int LSTM_ZCOLS = 64 * LSTM_NW;  // z columns per direction: wave*64 + gate*16 + (unit & 15)
 
 struct LstmParams {
-  const float* z;        // [T][BP/4][ndir][LSTM_ZCOLS][4 rows]  x-projection + bias, MFMA fragment order; direction 1 is
+  const float* z;        // [T][BP/4][ndir][4*H][4 rows]  x-projection + bias, column = gate*H + unit; direction 1 is
                          //   indexed by STEP (frame seq_len-1-s), direction 0 by frame
   const float* wfrag;    // [ndir][LSTM_NW][LSTM_K][64 lanes] recurrent weights, fragment order
   const int32_t* seq_len;  // [BP] (0 for padded rows)

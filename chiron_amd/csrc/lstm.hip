@@ -13,7 +13,7 @@
 //   not hide behind it; what counts is total issue time, and this layout needs ONE cell per lane.)
 //
 //   per step and row group:  acc[4 rows] (lane = gate*16 + unit)  <-  h_{t-1} . W_hh      100 MFMAs
-//                            + z_t (x-projection, produced by gemm.hip in exactly this fragment order)
+//                            + z_t (x-projection; gemm.hip stores it [col = gate*H + unit][4 rows], one 16-byte load per lane)
 //                            4x4 register transpose (lane swaps): lane (row, unit) gets i, j, f, o of its cell
 //                            c = sig(f)*c + sig(i)*tanh(j);  h = sig(o)*tanh(c)   (forget bias folded in z)
 //   h is exchanged through a double-buffered 2 KB LDS tile per group (A-operand order, see HG), one barrier per step.
@@ -93,9 +93,12 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
 
   // all offsets are 32-bit element indices (z: < 2^29 floats at B = 1100, T = 400): scalar base + one VGPR
   const unsigned outw = p.ndir * p.H;
-  const unsigned zstep = (p.BP >> 2) * p.ndir * LSTM_ZCOLS * 4;  // floats between consecutive steps
-  const unsigned zlane = ((g0 * p.ndir + dir) * LSTM_ZCOLS + wave * 64 + lane) * 4;
-  const unsigned zgrp = p.ndir * LSTM_ZCOLS * 4;                 // floats between consecutive row groups
+  // z column of this lane before the transpose (lane = gate*16 + unit): gate*H + unit, the plain TF kernel order;
+  // lanes of units past H read a valid column (their cells are never stored)
+  const unsigned zcols = 4 * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;  // floats between consecutive steps
+  const unsigned zlane = ((g0 * p.ndir + dir) * zcols + (lane >> 4) * p.H + min(wave * 16 + (lane & 15), p.H - 1)) * 4;
+  const unsigned zgrp = p.ndir * zcols * 4;                 // floats between consecutive row groups
   const unsigned ostep = p.BP * outw;                            // floats between consecutive frames of the output
   const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
   const int hw = ((lane & 15) * 4 + row) * 8 + wave;             // where this lane's cell writes h: blk = unit & 15, q = wave
@@ -222,8 +225,9 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
   __syncthreads();
 
   const unsigned outw = p.ndir * p.H;
-  const unsigned zstep = (p.BP >> 2) * p.ndir * LSTM_ZCOLS * 4;
-  const unsigned zlane_b = ((g0 * p.ndir + dir) * LSTM_ZCOLS + wave * 64 + lane) * 8;   // 4 halves per lane
+  const unsigned zcols = 4 * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;
+  const unsigned zlane_b = ((g0 * p.ndir + dir) * zcols + (lane >> 4) * p.H + min(wave * 16 + (lane & 15), p.H - 1)) * 8;   // 4 halves per lane
   const unsigned ostep = p.BP * outw;
   const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
   _Float16* outh = reinterpret_cast<_Float16*>(p.out);

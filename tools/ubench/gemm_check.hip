@@ -68,9 +68,9 @@ int main(int argc, char** argv) {
     }
     printf("conv  B=%d T=%d: max err %.3e at m=%ld n=%ld\n", B, T, worst, wm / C, wm % C);
   }
-  // ---- z layout: A = time-major [T][BP][200], K = 200 (pad 224), N = 896
+  // ---- z layout: A = time-major [T][BP][200], K = 200 (pad 224), N = 800 (six full tiles + one narrow)
   {
-    const int H2 = 200, N = 896, Kp = 224;
+    const int H2 = 200, N = 800, Kp = 224;
     std::vector<float> hL((long)T * BP * H2), hW2((long)N * Kp, 0.f);
     for (auto& v : hL) v = frand(s);
     for (int n = 0; n < N; ++n)
@@ -94,7 +94,7 @@ int main(int argc, char** argv) {
       hipMemcpy(seq, hs.data(), BP * 4, hipMemcpyHostToDevice);
     }
     g.z_seq_len = seq;  // all rows full length: the backward half is stored at step T-1-t
-    g.out = z; g.out_mode = 1; g.z_cols = 448; g.z_ndir = 2; g.z_dir0 = 0;
+    g.out = z; g.out_mode = 1; g.z_cols = 400; g.z_ndir = 2; g.z_dir0 = 0;
     launch_gemm(g, 0);
     hipDeviceSynchronize();
     std::vector<float> hz((long)T * BP * N);
@@ -106,9 +106,9 @@ int main(int argc, char** argv) {
         for (int n = 0; n < N; n += 29) {
           double acc = hS[n];
           for (int k = 0; k < H2; ++k) acc += (double)hL[((long)t * BP + b) * H2 + k] * hW2[(long)n * Kp + k];
-          const int dir = n / 448, nl = n % 448;
+          const int dir = n / 400, nl = n % 400;
           const int ts = dir == 0 ? t : T - 1 - t;
-          const float got = hz[((((long)ts * (BP / 4) + (b >> 2)) * 2 + dir) * 448 + nl) * 4 + (b & 3)];
+          const float got = hz[((((long)ts * (BP / 4) + (b >> 2)) * 2 + dir) * 400 + nl) * 4 + (b & 3)];
           const double e = fabs(acc - got);
           if (!(e <= worst)) { worst = e; wt_ = t; wb = b; wn = n; }
         }
