@@ -458,7 +458,7 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
     for (int pj = 0; pj < lp.nproj; ++pj) {
       const int ndir = split ? 1 : 2;
       const int N = ndir * zc;
-      const int Npad = roundup(N, GEMM_BN);
+      const int Npad = std::max(roundup(N, GEMM_BN), roundup(N, 160));  // the DMA kernel reads whole 160-row weight tiles
       std::vector<float> Wt((size_t)Npad * Kp, 0.f), sh(Npad, 0.f);
       for (int n = 0; n < N; ++n) {
         const int dir = split ? pj : n / zc;

@@ -98,10 +98,10 @@ struct RowSplit {
 // Epilogue of the DMA kernel for a tile that lies completely inside N: no per-store bounds checks or branches,
 // one base address per row (the stores use immediate offsets), ReLU as one v_med3 per value, shift already in
 // the accumulators.  ~100 VALU instructions per tile instead of ~350 -- they are all paid in matrix-pipe time.
-template <bool ZOUT, bool RES, bool RELU, int OUTFMT = 0>
+template <bool RES, bool RELU, int OUTFMT = 0>
 __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
                                                    int li, int kh) {
-  if (!ZOUT) {
+  {
     const RowSplit rs(m0, p.T_out);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -154,52 +154,34 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
         }
       }
     }
-  } else {
-    const RowSplit rs(m0, p.BP);
-    const int zcols = p.z_cols;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int dm = wm * 64 + mi * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows: one 4-row group of lstm.hip
-        if (m0 + dm >= p.M) continue;
-        int t, b;
-        rs.split(dm, t, b);
-        const ZGroup zg(p, t, b);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int n = n0 + wn * 64 + ni * 32 + li;
-          const int dir = p.z_dir0 + (n >= zcols ? 1 : 0);  // z_cols >= 128: a tile spans at most two directions
-          const int nl = n - (n >= zcols ? zcols : 0);
-          f32x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r];
-          zg.store(p, dir, nl, v);
-        }
-      }
-    }
   }
 }
 
-// Epilogue of a NARROW projection tile (at most 32 live columns: the last N tile of the 800- or 400-column LSTM
-// projection).  The four waves split the 128 rows instead of the columns: wave w owns rows 32w .. 32w+31 and ONE
-// 32x32 accumulator, so the tile costs a quarter of the MFMAs of a full one instead of all of them.
-__device__ __forceinline__ void gemm_epilogue_narrow(const GemmParams& p, const f32x16& acc, int m0, int n0, int wave, int li, int kh) {
-  const int n = n0 + li;
-  if (n >= p.N) return;
-  const int dir = p.z_dir0 + n / p.z_cols;
-  const int nl = n % p.z_cols;
+// Epilogue of the projection (ZOUT) layout of the DMA kernel: a 128 x 160 tile whose four waves split the ROWS (wave w
+// owns rows 32w .. 32w+31 and all 160 columns = five 32x32 accumulators), so that N = 800 = 8H is five whole tiles.
+// A lane holds 4 consecutive rows (one 4-row group of lstm.hip) of one column per register quad: one 16-byte store.
+template <int NNI>
+__device__ __forceinline__ void gemm_epilogue_zrows(const GemmParams& p, f32x16 (&acc)[1][NNI], int m0, int n0, int wave, int li, int kh) {
   const RowSplit rs(m0, p.BP);
+  const int zcols = p.z_cols;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int dm = wave * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows: one 4-row group of lstm.hip
+    const int dm = wave * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows
     if (m0 + dm >= p.M) continue;
     int t, b;
     rs.split(dm, t, b);
-    f32x4 v;
+    const ZGroup zg(p, t, b);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[4 * q + r];
-    ZGroup(p, t, b).store(p, dir, nl, v);
+    for (int ni = 0; ni < NNI; ++ni) {
+      const int n = n0 + ni * 32 + li;
+      if (n >= p.N) continue;
+      const int dir = p.z_dir0 + (n >= zcols ? 1 : 0);  // z_cols >= 160: a tile spans at most two directions
+      const int nl = n - (n >= zcols ? zcols : 0);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[0][ni][4 * q + r];
+      zg.store(p, dir, nl, v);
+    }
   }
 }
 
@@ -524,7 +506,7 @@ constexpr unsigned DMA_OOB = 0xFFFF0000u;      // >= num_records with any immedi
 constexpr unsigned DMA_RECORDS = 0xFFFE0000u;  // every tensor of the engine is smaller than this many bytes
 struct DmaSrc {
   unsigned aoff[4];  // per piece: byte offset (from the segment's tensor) of this lane's 16 bytes for chunk 0, or DMA_OOB
-  unsigned boff[4];  // same for the weights
+  unsigned boff[5];  // same for the weights (5 pieces of 8 rows per wave in the 160-column projection layout)
   __amdgpu_buffer_rsrc_t ra, rb;
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base) {
@@ -542,10 +524,10 @@ __device__ __forceinline__ void dma_piece(const DmaSrc& L, int q, float* a_dst, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(L.rb, (lptr_t)(b_dst + (q - 4) * 256 - C * GEMM_BK), 16, L.boff[q - 4], 0,
                                              C * GEMM_BK * 4, 0);
 }
-template <int C>
+template <int C, int NP>
 __device__ __forceinline__ void dma_issue(const DmaSrc& L, float* a_dst, float* b_dst) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) dma_piece<C>(L, q, a_dst, b_dst);
+  for (int q = 0; q < NP; ++q) dma_piece<C>(L, q, a_dst, b_dst);
 }
 
 // CPS = chunks per K-segment (every segment of a launch has the same width), TAIL = the segment's channel
@@ -556,10 +538,18 @@ template <bool ZOUT, bool RES, int CPS, bool TAIL, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p) {
   constexpr bool F16 = MODE == 1;
   constexpr bool SPLIT = MODE == 2;
-  __shared__ __attribute__((aligned(16))) float lds[DMA_PAD_F + 4 * DTILE_F + DMA_MAX_N];  // pad A0 A1 B0 B1 shift
+  // Wave layout.  Convolutions: 128 x 128 tile, waves 2 x 2, each 64 x 64 (2 x 2 accumulators).  Projections (ZOUT):
+  // 128 x 160 tile, waves 4 x 1, each 32 rows x 160 columns (1 x 5 accumulators) -- N = 8H = 800 is then five whole
+  // tiles instead of 6.25 tiles of 128.
+  constexpr int BN = ZOUT ? 160 : GEMM_BN;      // tile columns = rows of the weight tile
+  constexpr int NMI = ZOUT ? 1 : 2, NNI = ZOUT ? 5 : 2;
+  constexpr int NBP = BN / 32;                  // DMA pieces (8 rows each) of the weight tile per wave and chunk
+  constexpr int NP = 4 + NBP;                   // DMA instructions per wave and chunk
+  constexpr int BTILE_F = BN * GEMM_BK;         // floats per weight tile
+  __shared__ __attribute__((aligned(16))) float lds[DMA_PAD_F + 2 * DTILE_F + 2 * BTILE_F + DMA_MAX_N];  // pad A0 A1 B0 B1 shift
   float* const As = lds + DMA_PAD_F;
   float* const Bs = As + 2 * DTILE_F;
-  float* const shl = Bs + 2 * DTILE_F;  // per-column shift (folded BN offset / LSTM bias), zero past N
+  float* const shl = Bs + 2 * BTILE_F;  // per-column shift (folded BN offset / LSTM bias), zero past N
 
   const int tid = threadIdx.x;
   // The tiles are only ever written by the DMA engine, which the optimiser does not see as a store to `lds`;
@@ -568,11 +558,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   for (int n = tid; n < DMA_MAX_N; n += 256) shl[n] = n < p.N ? p.shift[n] : 0.f;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = ZOUT ? wave : wave >> 1, wn = ZOUT ? 0 : wave & 1;
   const int li = lane & 31;
   const int kh = lane >> 5;
 
-  const int nblocks_n = (p.N + GEMM_BN - 1) / GEMM_BN;
+  const int nblocks_n = (p.N + BN - 1) / BN;
   const int mblocks = (p.M + GEMM_BM - 1) / GEMM_BM;
   const int total_ids = ((mblocks + 7) / 8) * 8 * nblocks_n;
   const int nseg = p.nseg;
@@ -582,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     const int slot = id >> 3;
     const int mblk = (slot / nblocks_n) * 8 + xcd;
     m0 = mblk * GEMM_BM;
-    n0 = (slot % nblocks_n) * GEMM_BN;
+    n0 = (slot % nblocks_n) * BN;
     return mblk < mblocks;
   };
   auto next_valid = [&](int id) -> int {  // next tile id of this workgroup after `id`, or total_ids
@@ -592,11 +582,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     return id;
   };
 
-  // ---- DMA geometry: piece j (0..3) of wave w covers tile rows w*32 + j*8 .. +7; lane -> (row, slot)
+  // ---- DMA geometry: piece j (0..3) of wave w covers tile rows w*32 + j*8 .. +7; lane -> (row, slot).  The physical
+  //      16-byte slot of logical slot s in tile row r is s ^ ((r >> 1) & 7).
   const int drow = wave * 32 + (lane >> 3);           // + 8*j
   int dslot[4];                                       // logical k-slot fetched into physical slot lane&7
 #pragma unroll
   for (int j = 0; j < 4; ++j) dslot[j] = ((lane & 7) ^ ((j * 4 + (lane >> 4)) & 7)) * 4;  // in floats
+  //      weight tile: wave w covers its rows w*BN/4 + j*8 .. +7, j < NBP (BN/4 = 32: same slots as A; 40: shifted by 4w)
+  const int bdrow = wave * (BN / 4) + (lane >> 3);    // + 8*j
+  int bslot[NBP];
+#pragma unroll
+  for (int j = 0; j < NBP; ++j) bslot[j] = ((lane & 7) ^ (((wave * (BN / 4) + j * 8 + (lane >> 3)) >> 1) & 7)) * 4;
   // fragment reads: physical slot of logical slot (2g+kh) for this lane's row
   int fslot[4];
 #pragma unroll
@@ -608,14 +604,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   L.ra = L.rb;
   int rb[4], rt[4];
   bool rvalid[4];
-  unsigned brow[4];
+  unsigned brow[NBP];
   auto load_tile = [&](int id) {
     int m0, n0;
     tile_of(id, m0, n0);
     const RowSplit rs(m0, ZOUT ? p.BP : p.T_out);
 #pragma unroll
+    for (int j = 0; j < NBP; ++j) brow[j] = (unsigned)((n0 + bdrow + 8 * j) * p.K + bslot[j]) * 4u;
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
-      brow[j] = (unsigned)((n0 + drow + 8 * j) * p.K + dslot[j]) * 4u;
       const int m = m0 + drow + 8 * j;
       bool v = m < p.M;
       int b, t;
@@ -638,8 +635,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
       const bool ok = rvalid[j] && in_t >= 0 && in_t < sg.w_in;
       const long row = sg.time_major ? ((long)in_t * p.BP + rb[j]) : ((long)rb[j] * sg.w_in + in_t);
       L.aoff[j] = ok ? (unsigned)((row * sg.lda + sg.col0 + dslot[j]) * 4) : DMA_OOB;
-      L.boff[j] = brow[j] + (unsigned)k0 * 4u;
     }
+#pragma unroll
+    for (int j = 0; j < NBP; ++j) L.boff[j] = brow[j] + (unsigned)k0 * 4u;
   };
   // chunk c of a segment whose channel count is not a multiple of 32: per-lane select against the K tail
   auto tail_piece = [&](int c, int cin, int q, float* a_dst, float* b_dst) {
@@ -653,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   };
   auto dma_issue_tail = [&](int c, int cin, float* a_dst, float* b_dst) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) tail_piece(c, cin, q, a_dst, b_dst);
+    for (int q = 0; q < NP; ++q) tail_piece(c, cin, q, a_dst, b_dst);
   };
 
   int c_id = blockIdx.x;
@@ -666,29 +664,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   load_tile(c_id);
   load_segment(p.seg[0], 0);
   if (TAIL && !SPLIT && CPS == 1)
-    dma_issue_tail(0, p.seg[0].cin, As + wave * 1024, Bs + wave * 1024);
+    dma_issue_tail(0, p.seg[0].cin, As + wave * 1024, Bs + wave * (BTILE_F / 4));
   else
-    dma_issue<0>(L, As + wave * 1024, Bs + wave * 1024);
+    dma_issue<0, NP>(L, As + wave * 1024, Bs + wave * (BTILE_F / 4));
   int buf = 0;
   bool have_prev = false;
   int pm0 = 0, pn0 = 0;
-  f32x16 acc[2][2];
+  f32x16 acc[NMI][NNI];
   const bool relu = p.relu != 0;
   // real work of the last chunk of a segment: 8-column groups (fp32 / f16 units), or 16-element k-steps (split)
   const int tail_groups = TAIL ? (p.seg[0].cin - (CPS - 1) * GEMM_BK + (SPLIT ? 15 : 7)) / (SPLIT ? 16 : 8) : 4;
-  bool pnarrow = false;
   auto epilogue = [&](int em0, int en0) {
-    if (ZOUT && pnarrow) {
-      gemm_epilogue_narrow(p, acc[0][0], em0, en0, wave, li, kh);
-      return;
-    }
-    if (((F16 || SPLIT) && !ZOUT) || (en0 + GEMM_BN <= p.N && (!ZOUT || 2 * p.z_cols >= p.N))) {  // f16 / split conv: N % 128 == 0 (launch_gemm)
-      if (relu)
-        gemm_epilogue_lean<ZOUT, RES, true, ZOUT ? 0 : MODE>(p, acc, em0, en0, wm, wn, li, kh);
-      else
-        gemm_epilogue_lean<ZOUT, RES, false, ZOUT ? 0 : MODE>(p, acc, em0, en0, wm, wn, li, kh);
+    if constexpr (ZOUT) {
+      gemm_epilogue_zrows<NNI>(p, acc, em0, en0, wave, li, kh);
     } else {
-      gemm_epilogue<ZOUT, RES, 0, 16, false>(p, acc, em0, en0, wm, wn, li, kh);
+      if (F16 || SPLIT || en0 + GEMM_BN <= p.N) {  // f16 / split conv: N % 128 == 0 (launch_gemm)
+        if (relu)
+          gemm_epilogue_lean<RES, true, MODE>(p, acc, em0, en0, wm, wn, li, kh);
+        else
+          gemm_epilogue_lean<RES, false, MODE>(p, acc, em0, en0, wm, wn, li, kh);
+      } else {
+        gemm_epilogue<false, RES, 0, 16, false>(p, acc, em0, en0, wm, wn, li, kh);
+      }
     }
   };
 
@@ -701,8 +698,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     tile_of(c_id, m0, n0);
     const int n_id = next_valid(c_id);
     int k0 = 0;
-    // last N tile of an LSTM projection with <= 32 live columns: the waves split the rows (gemm_epilogue_narrow)
-    const bool narrow = ZOUT && p.N - n0 <= 32;
 
     auto segment = [&](auto first_tag, int sgi) {
       constexpr bool FS = decltype(first_tag)::value;  // first K-segment of the tile
@@ -714,8 +709,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
         constexpr int C = decltype(cc)::value;
         __syncthreads();  // chunk in `buf` has landed (vmcnt drained before the barrier); buf^1 is free
         float* a_dst = As + (buf ^ 1) * DTILE_F + wave * 1024;  // wave-uniform bases; lanes land at +16 B each
-        float* b_dst = Bs + (buf ^ 1) * DTILE_F + wave * 1024;
-        // The 8 DMA instructions of the next chunk are interleaved with the first 32 MFMAs below instead of
+        float* b_dst = Bs + (buf ^ 1) * BTILE_F + wave * (BTILE_F / 4);
+        // The NP (8 or 9) DMA instructions of the next chunk are interleaved with the first MFMAs below instead of
         // being issued in a burst (all eight waves of the CU share one texture-address unit).
         bool go = true;
         if (C + 1 == CPS) {  // first chunk of the next segment / of the next tile: new per-lane pointers
@@ -742,13 +737,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
               dma_piece<0>(L, q, a_dst, b_dst);
           }
         };
-        f32x16 ini[2];
+        f32x16 ini[NNI];
         if (FS && C == 0) {
-          // C operand of the tile's first MFMAs: this lane's 16 shift values per 32-column half
+          // C operand of the tile's first MFMAs: this lane's 16 shift values per 32-column block
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
+          for (int ni = 0; ni < NNI; ++ni) {
             if (ZOUT) {
-              const float sh = shl[n0 + (narrow ? 0 : wn * 64) + ni * 32 + li];
+              const float sh = shl[n0 + ni * 32 + li];
 #pragma unroll
               for (int r = 0; r < 16; ++r) ini[ni][r] = sh;
             } else {
@@ -764,11 +759,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
           // vmcnt(0) then only ever waits for DMA issued a whole chunk earlier, never for fresh stores.
           if (have_prev) epilogue(pm0, pn0);
         }
-        auto mma = [&](auto narrow_tag) {
-          constexpr bool NW = decltype(narrow_tag)::value;  // narrow tile: wave w -> rows 32w.., columns 0..31
-          constexpr int NMI = NW ? 1 : 2, NNI = NW ? 1 : 2;
-          const float* a0 = As + buf * DTILE_F + ((NW ? wave * 32 : wm * 64) + li) * GEMM_BK;
-          const float* b0 = Bs + buf * DTILE_F + ((NW ? 0 : wn * 64) + li) * GEMM_BK;
+        {
+          const float* a0 = As + buf * DTILE_F + (wm * (NMI * 32) + li) * GEMM_BK;
+          const float* b0 = Bs + buf * BTILE_F + (wn * (NNI * 32) + li) * GEMM_BK;
           if (SPLIT) {
             // A 128-byte row chunk = 32 elements: slots 0-3 hold the hi halves of elements 0-7 / 8-15 / 16-23 / 24-31,
             // slots 4-7 the lo halves.  k-step s (16 elements) uses hi slot 2s+kh and lo slot 4+2s+kh, i.e. the fp32
@@ -776,9 +769,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) piece(st * 4 + j);
+              for (int j = 0; j < (st == 1 ? NP - 4 : 4); ++j) piece(st * 4 + j);
               if (TAIL && C + 1 == CPS && st >= tail_groups) continue;  // tail_groups counts 16-element k-steps here
-              f32x4 ah[2], al[2], bh[2], bl[2];
+              f32x4 ah[NMI], al[NMI], bh[NNI], bl[NNI];
 #pragma unroll
               for (int mi = 0; mi < NMI; ++mi) {
                 ah[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st]);
@@ -813,13 +806,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
           for (int g = 0; g < 4; ++g) {
             // K tail: the last chunk of a segment holds only tail_groups * 8 real columns, the rest multiplies zeros
             if (TAIL && C + 1 == CPS && g >= tail_groups) {  // nothing but zeros to multiply: only the DMA pieces this group carries
-              if (g < 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) piece(g * 4 + j);
-              }
+              for (int j = 0; j < 4; ++j)
+                if (g * 4 + j < NP) piece(g * 4 + j);
               continue;
             }
-            f32x4 a[2], b[2];
+            f32x4 a[NMI], b[NNI];
 #pragma unroll
             for (int mi = 0; mi < NMI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[g]);
 #pragma unroll
@@ -828,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
               // 16 bytes = the 8 halves of one k-step of v_mfma_f32_32x32x16_f16 (lanes 0-31: k 0-7, lanes 32-63: k 8-15)
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                if (g < 2) piece(g * 4 + j);
+                if (g * 4 + j < NP) piece(g * 4 + j);
 #pragma unroll
               for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
@@ -841,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                if (g < 2) piece(g * 4 + j);
+                if (g * 4 + j < NP) piece(g * 4 + j);
 #pragma unroll
                 for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
@@ -854,11 +846,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
             }
           }
           }
-        };
-        if (ZOUT && narrow)
-          mma(std::true_type{});
-        else
-          mma(std::false_type{});
+        }
         buf ^= 1;
       };
       chunk(std::integral_constant<int, 0>{});
@@ -874,7 +862,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     for (int sgi = 1; sgi < nseg; ++sgi) segment(std::false_type{}, sgi);
 
     have_prev = true;
-    pnarrow = narrow;
     pm0 = m0;
     pn0 = n0;
     c_id = n_id;
@@ -887,7 +874,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
 template <bool ZOUT, bool RES>
 static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t stream) {
   const int kpad = p.seg[0].kpad, cin = p.seg[0].cin;
-  if (((p.N + GEMM_BN - 1) / GEMM_BN) * GEMM_BN > DMA_MAX_N) return false;
+  constexpr int BN = ZOUT ? 160 : GEMM_BN;
+  if (((p.N + BN - 1) / BN) * BN > DMA_MAX_N) return false;
+  if (ZOUT && p.z_cols < BN) return false;  // a projection tile may span at most two directions
   for (int s = 1; s < p.nseg; ++s)
     if (p.seg[s].kpad != kpad || p.seg[s].cin != cin) return false;
   const bool tail = cin != kpad;
@@ -957,20 +946,23 @@ bool launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  int g = 2 * n_cu;            // two resident workgroups per CU (65 KB LDS each)
+  int g = 2 * n_cu;            // two resident workgroups per CU (69 KB LDS each; 77 KB for the projection layout)
   g = (g / 8) * 8;
   if (g > total_ids) g = total_ids;
   const dim3 grid(g), block(256);
+  // projections run 128 x 160 tiles on the DMA kernel
+  const int total_z = ((mblocks + 7) / 8) * 8 * ((p.N + 159) / 160);
+  const dim3 grid_z(std::min((2 * n_cu / 8) * 8, total_z));
   if (p.f16) {  // halves: only the DMA kernels exist
     if (p.seg[0].src == nullptr) return false;
-    if (p.out_mode == 1) return launch_dma<true, false>(p, grid, block, stream);
+    if (p.out_mode == 1) return launch_dma<true, false>(p, grid_z, block, stream);
     if (p.res_a != nullptr) return launch_dma<false, true>(p, grid, block, stream);
     return launch_dma<false, false>(p, grid, block, stream);
   }
   if (p.seg[0].src == nullptr) {  // lifted signal: A is computed in the loader
     hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, block, 0, stream, p);
   } else if (p.out_mode == 1) {
-    if (!launch_dma<true, false>(p, grid, block, stream))
+    if (!launch_dma<true, false>(p, grid_z, block, stream))
       hipLaunchKernelGGL((gemm_f32_kernel<false, true, false>), grid, block, 0, stream, p);
   } else if (p.res_a != nullptr) {
     if (!launch_dma<false, true>(p, grid, block, stream))

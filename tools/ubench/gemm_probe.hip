@@ -72,5 +72,45 @@ int main(int argc, char** argv) {
     for (int i = 0; i < (1 << 18); ++i) sum += h[i];
     printf("%s K=%d: %.4f ms  %.1f TFLOP/s  (checksum %.6e)\n", argc > 1 ? argv[1] : "", g.K, ms, 2.0 * M * C * g.K / ms * 1e-9, sum);
   }
+  // ---- LSTM x-projection: A = time-major [T][BP][200] (K = 200, padded 224), N = 800, z layout of lstm.hip
+  if (getenv("PROBE_ZOUT")) {
+    const int BP = (B + 3) / 4 * 4, H2 = 200, N = 800, Kp = 224;
+    float *la, *w2, *z, *sh2;
+    int* seq;
+    hipMalloc(&la, (long)T * BP * H2 * 4);
+    hipMalloc(&w2, (long)896 * Kp * 4);
+    hipMalloc(&z, (long)T * BP * N * 4);
+    hipMalloc(&sh2, 1024 * 4);
+    hipMalloc(&seq, BP * 4);
+    hipMemcpy(la, h.data(), (long)T * BP * H2 * 4, hipMemcpyHostToDevice);
+    hipMemset(w2, 0, (long)896 * Kp * 4);
+    hipMemcpy(w2, h.data(), (long)N * Kp * 4, hipMemcpyHostToDevice);
+    hipMemset(sh2, 0, 1024 * 4);
+    {
+      std::vector<int> hs(BP, T);
+      hipMemcpy(seq, hs.data(), BP * 4, hipMemcpyHostToDevice);
+    }
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.BP = BP; g.N = N; g.K = Kp; g.Wt = w2; g.shift = sh2; g.z_dirs_total = 2;
+    g.M = T * BP; g.T_out = T; g.m_time_major = 1; g.nseg = 1;
+    g.seg[0] = GemmSeg{la, H2, 0, H2, Kp, T, 1, 0, 1};
+    g.z_seq_len = seq;
+    g.out = z; g.out_mode = 1; g.z_cols = 400; g.z_ndir = 2; g.z_dir0 = 0;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch_gemm(g, 0);
+    hipDeviceSynchronize();
+    const int reps = 20;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) launch_gemm(g, 0);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("%s zproj K=200 N=800: %.4f ms  %.1f TFLOP/s\n", argc > 1 ? argv[1] : "", ms, 2.0 * T * B * N * H2 / ms * 1e-9);
+  }
   return 0;
 }
