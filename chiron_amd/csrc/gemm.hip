@@ -160,29 +160,76 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
 // Epilogue of the projection (ZOUT) layout of the DMA kernel: a 128 x 160 tile whose four waves split the ROWS (wave w
 // owns rows 32w .. 32w+31 and all 160 columns = five 32x32 accumulators), so that N = 800 = 8H is five whole tiles.
 // A lane holds 4 consecutive rows (one 4-row group of lstm.hip) of one column per register quad: one 16-byte store.
-template <int NNI>
-__device__ __forceinline__ void gemm_epilogue_zrows(const GemmParams& p, f32x16 (&acc)[1][NNI], int m0, int n0, int wave, int li, int kh) {
+// Every per-store instruction is paid NNI * 4 times per lane and tile in matrix-pipe time, so the three common cases
+// are decided once per wave / per 4-row group: forward-only tiles (no lengths, no predicates, five stores off one
+// pointer), backward-only tiles whose groups have equal lengths (one predicate per group), and the general path.
+template <int NNI, bool ZF16>
+__device__ __forceinline__ void gemm_epilogue_zrows_t(const GemmParams& p, f32x16 (&acc)[1][NNI], int m0, int n0, int wave, int li, int kh) {
+  typedef typename std::conditional<ZF16, _Float16, float>::type elem_t;
+  typedef typename std::conditional<ZF16, f16x4, f32x4>::type vec_t;
   const RowSplit rs(m0, p.BP);
   const int zcols = p.z_cols;
+  const unsigned gstride = (unsigned)p.z_dirs_total * zcols * 4;  // elements per 4-row group
+  const unsigned per_t = (unsigned)(p.BP >> 2) * gstride;         // elements per step
+  elem_t* const out0 = reinterpret_cast<elem_t*>(p.out) + (unsigned)(p.z_dir0 * zcols + n0 + li) * 4;  // this lane's column of block ni = 0
+  const bool full_n = n0 + NNI * 32 <= p.N;
+  const bool all_fwd = full_n && p.z_dir0 == 0 && n0 + NNI * 32 <= zcols;  // wave-uniform
+  const bool all_bwd = full_n && (p.z_dir0 > 0 || n0 >= zcols);
+  auto vec = [&](int ni, int q) {
+    vec_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (elem_t)acc[0][ni][4 * q + r];
+    return v;
+  };
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int dm = wave * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows
     if (m0 + dm >= p.M) continue;
     int t, b;
     rs.split(dm, t, b);
-    const ZGroup zg(p, t, b);
+    elem_t* const og = out0 + (unsigned)(b >> 2) * gstride;
+    if (all_fwd) {
+      elem_t* const o = og + (unsigned)t * per_t;
+#pragma unroll
+      for (int ni = 0; ni < NNI; ++ni) *reinterpret_cast<vec_t*>(o + ni * 128) = vec(ni, q);
+      continue;
+    }
+    const int4 len = *reinterpret_cast<const int4*>(p.z_seq_len + b);
+    const int l0 = min(len.x, p.T_out), l1 = min(len.y, p.T_out), l2 = min(len.z, p.T_out), l3 = min(len.w, p.T_out);
+    const bool uniform = l0 == l1 && l1 == l2 && l2 == l3;
+    if (all_bwd && uniform) {
+      if (t < l0) {
+        elem_t* const o = og + (unsigned)(l0 - 1 - t) * per_t;
+#pragma unroll
+        for (int ni = 0; ni < NNI; ++ni) *reinterpret_cast<vec_t*>(o + ni * 128) = vec(ni, q);
+      }
+      continue;
+    }
 #pragma unroll
     for (int ni = 0; ni < NNI; ++ni) {
       const int n = n0 + ni * 32 + li;
       if (n >= p.N) continue;
-      const int dir = p.z_dir0 + (n >= zcols ? 1 : 0);  // z_cols >= 160: a tile spans at most two directions
-      const int nl = n - (n >= zcols ? zcols : 0);
-      f32x4 v;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[0][ni][4 * q + r];
-      zg.store(p, dir, nl, v);
+      elem_t* const o = og + ni * 128;
+      const vec_t v = vec(ni, q);
+      if (p.z_dir0 == 0 && n < zcols) {
+        *reinterpret_cast<vec_t*>(o + (unsigned)t * per_t) = v;
+      } else if (uniform) {
+        if (t < l0) *reinterpret_cast<vec_t*>(o + (unsigned)(l0 - 1 - t) * per_t) = v;
+      } else {
+        if (t < l0) o[(unsigned)(l0 - 1 - t) * per_t + 0] = v[0];
+        if (t < l1) o[(unsigned)(l1 - 1 - t) * per_t + 1] = v[1];
+        if (t < l2) o[(unsigned)(l2 - 1 - t) * per_t + 2] = v[2];
+        if (t < l3) o[(unsigned)(l3 - 1 - t) * per_t + 3] = v[3];
+      }
     }
   }
+}
+template <int NNI>
+__device__ __forceinline__ void gemm_epilogue_zrows(const GemmParams& p, f32x16 (&acc)[1][NNI], int m0, int n0, int wave, int li, int kh) {
+  if (p.z_f16)
+    gemm_epilogue_zrows_t<NNI, true>(p, acc, m0, n0, wave, li, kh);
+  else
+    gemm_epilogue_zrows_t<NNI, false>(p, acc, m0, n0, wave, li, kh);
 }
 
 // Stores LO <= idx < HI of the 16 16-byte stores a lane owns (idx = (outer*2 + inner)*4 + q): the DMA kernel
