@@ -19,20 +19,21 @@ using namespace chiron;
 int main(int argc, char** argv) {
   const int B = getenv("PROBE_B") ? atoi(getenv("PROBE_B")) : 1100, T = 400, C = 256;
   const long M = (long)B * T;
+  const int LD = C + (getenv("PROBE_LDPAD") ? atoi(getenv("PROBE_LDPAD")) : 0);  // row stride of the activations
   float *act, *out, *wt, *shift, *zero;
-  hipMalloc(&act, M * C * 4);
-  hipMalloc(&out, M * C * 4);
+  hipMalloc(&act, M * LD * 4);
+  hipMalloc(&out, M * LD * 4);
   hipMalloc(&wt, 2048 * 256 * 4);
   hipMalloc(&shift, 256 * 4);
   hipMalloc(&zero, 4096);
   hipMemset(zero, 0, 4096);
-  std::vector<float> h(M * C);
+  std::vector<float> h(M * LD);
   unsigned s = 12345;
   for (auto& v : h) {
     s = s * 1664525u + 1013904223u;
     v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
   }
-  hipMemcpy(act, h.data(), M * C * 4, hipMemcpyHostToDevice);
+  hipMemcpy(act, h.data(), M * LD * 4, hipMemcpyHostToDevice);
   hipMemcpy(wt, h.data(), 2048 * 256 * 4, hipMemcpyHostToDevice);
   hipMemcpy(shift, h.data(), 256 * 4, hipMemcpyHostToDevice);
 
@@ -50,10 +51,10 @@ int main(int argc, char** argv) {
     g.M = (int)M;
     g.T_out = T;
     g.nseg = ntap;
-    for (int j = 0; j < ntap; ++j) g.seg[j] = GemmSeg{act, C, 0, C, C, T, 1, j - ntap / 2, 0};
+    for (int j = 0; j < ntap; ++j) g.seg[j] = GemmSeg{act, LD, 0, C, C, T, 1, j - ntap / 2, 0};
     g.relu = 1;
     g.out = out;
-    g.ldo = C;
+    g.ldo = LD;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
