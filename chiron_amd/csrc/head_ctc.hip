@@ -20,35 +20,43 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // --------------------------------------------------------------------------------------------
 // FC head.  logits[b][t][k] = sum_u (h_fw[u]*w[0][u] + h_bw[u]*w[1][u] + bias[u]) * wc[u][k] + bc[k]
-// One wave per position (t,b): lanes 0..2H/4-1 each own 4 consecutive columns of the 2H-wide row.
+// HBM-bound (reads lasth once).  16 lanes per position (t, b), four positions -- four consecutive batch rows of one
+// frame, 4 x 800 contiguous bytes of the time-major lasth -- per wave and iteration: lane sl of a group owns the
+// float4 column groups sl, sl+16, sl+32, sl+48 (< 2H/4) of its row, the 16-lane sums are four DPP row rotations per
+// class (a 64-lane butterfly per position cost 6 cross-lane steps per class and made the kernel issue-bound).
 // --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
 __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
   const int lane = threadIdx.x & 63;
+  const int sub = lane >> 4, sl = lane & 15;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int H = p.H, K = p.K;
-  const int nl = (2 * H) / 4;  // lanes carrying data (50 for H=100)
+  const int nl = (2 * H) / 4;  // float4 column groups of a row (50 for H=100; <= 64)
 
-  // per-lane folded weights: cw[j][k] = w[dir][u_j] * wc[u_j][k]
-  float cw[4][CHIRON_KMAX];
-  float cst[CHIRON_KMAX];
+  // per-lane folded weights: cw[s][j][k] = w[dir][u] * wc[u][k] for column 4*(sl + 16 s) + j
+  float cw[4][4][CHIRON_KMAX];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int k = 0; k < CHIRON_KMAX; ++k) cw[j][k] = 0.f;
-  if (lane < nl) {
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int cidx = 4 * lane + j;  // column in [0, 2H)
-      const int d = cidx / H;
-      const int u = cidx - d * H;
-      const float wd = p.w[d * H + u];
+      const int cidx = 4 * (sl + 16 * s) + j;  // column in [0, 2H)
+      const bool ok = sl + 16 * s < nl;
+      const int d = ok ? cidx / H : 0;
+      const int u = ok ? cidx - d * H : 0;
+      const float wd = ok ? p.w[d * H + u] : 0.f;
 #pragma unroll
-      for (int k = 0; k < CHIRON_KMAX; ++k)
-        if (k < K) cw[j][k] = wd * p.wc[u * K + k];
+      for (int k = 0; k < CHIRON_KMAX; ++k) cw[s][j][k] = (ok && k < K) ? wd * p.wc[u * K + k] : 0.f;
     }
-  }
   // constant term: sum_u bias[u]*wc[u][k] + bc[k]  (same for every position)
+  float cst[CHIRON_KMAX];
 #pragma unroll
   for (int k = 0; k < CHIRON_KMAX; ++k) {
     float s = 0.f;
@@ -59,41 +67,56 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
     cst[k] = (k < K) ? s + p.bc[k] : 0.f;
   }
 
-  const long npos = (long)p.T * p.B;
-  for (long pos = wave; pos < npos; pos += nwaves) {
-    const int b = (int)(pos / p.T);
-    const int t = (int)(pos - (long)b * p.T);
-    f32x4 h = {0.f, 0.f, 0.f, 0.f};
-    if (lane < nl) {
-      if (p.split) {
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        const int col = 4 * lane;  // 4 consecutive columns never straddle a 32-element block
-        const _Float16* q = reinterpret_cast<const _Float16*>(p.lasth) + (((long)t * p.BP + b) * p.ld + (col >> 5) * 32) * 2 + (col & 31);
-        const f16x4 hi = *reinterpret_cast<const f16x4*>(q), lo = *reinterpret_cast<const f16x4*>(q + 32);
-        h = (f32x4){(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
-      } else if (p.f16) {
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        const f16x4 hh = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.lasth) + ((long)t * p.BP + b) * 2 * H + 4 * lane);
-        h = (f32x4){(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]};
-      } else {
-        h = *reinterpret_cast<const f32x4*>(p.lasth + ((long)t * p.BP + b) * 2 * H + 4 * lane);
+  const int nb4 = (p.B + 3) >> 2;
+  const int nunits = p.T * nb4;  // (frame, 4-row group)
+  auto load_unit = [&](int q, f32x4 (&h)[4]) {
+    const int t = q / nb4;
+    const int b = (q - t * nb4) * 4 + sub;
+    const long row = (long)t * p.BP + (b < p.B ? b : 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      h[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int f = sl + 16 * s;
+      if (f < nl) {
+        if (p.split) {
+          typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+          const int col = 4 * f;  // 4 consecutive columns never straddle a 32-element block
+          const _Float16* hq = reinterpret_cast<const _Float16*>(p.lasth) + (row * p.ld + (col >> 5) * 32) * 2 + (col & 31);
+          const f16x4 hi = *reinterpret_cast<const f16x4*>(hq), lo = *reinterpret_cast<const f16x4*>(hq + 32);
+          h[s] = (f32x4){(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+        } else if (p.f16) {
+          typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+          const f16x4 hh = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.lasth) + row * 2 * H + 4 * f);
+          h[s] = (f32x4){(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]};
+        } else {
+          h[s] = *reinterpret_cast<const f32x4*>(p.lasth + row * 2 * H + 4 * f);
+        }
       }
     }
-    float acc[CHIRON_KMAX];
+  };
+  f32x4 hn[4];
+  if (wave < nunits) load_unit(wave, hn);
+  for (int q = wave; q < nunits; q += nwaves) {
+    const int t = q / nb4;
+    const int b = (q - t * nb4) * 4 + sub;
+    const bool live = b < p.B;
+    f32x4 h[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) h[s] = hn[s];
+    if (q + nwaves < nunits) load_unit(q + nwaves, hn);  // the next unit's rows are in flight during this one's arithmetic
+    float v = 0.f;
 #pragma unroll
     for (int k = 0; k < CHIRON_KMAX; ++k) {
-      float s = 0.f;
+      if (k >= K) break;
+      float a = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s = fmaf(h[j], cw[j][k], s);
-      acc[k] = wave_sum(s);
-    }
-    if (lane < K) {
-      float v = 0.f;
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int k = 0; k < CHIRON_KMAX; ++k)
-        if (lane == k) v = acc[k] + cst[k];
-      p.logits[pos * K + lane] = v;
+        for (int j = 0; j < 4; ++j) a = fmaf(h[s][j], cw[s][j][k], a);
+      a = row16_sum(a);
+      if (sl == k) v = a + cst[k];
     }
+    if (live && sl < K) p.logits[((long)b * p.T + t) * K + sl] = v;
   }
 }
 
