@@ -154,7 +154,9 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
       }
     }
 #undef CHIRON_MF
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[0]));
+#pragma unroll
+    for (int g = 0; g < NG; ++g)  // tied to the accumulators as well: the scheduler must not move the wait ahead of the MFMAs
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[g]), "+v"(acc[g]));
     // ---- gates: transpose (lane = gate*16+unit, reg = row) -> (lane = row*16+unit, reg = gate)
     float* hn = hbuf + (cur ^ 1) * (NG * HG);
 #pragma unroll
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
     CHIRON_MF16(16) CHIRON_MF16(17) CHIRON_MF16(18) CHIRON_MF16(19) CHIRON_MF16(20) CHIRON_MF16(21) CHIRON_MF16(22) CHIRON_MF16(23)
     CHIRON_MF16(24)
 #undef CHIRON_MF16
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh), "+v"(acc0), "+v"(acc1));  // tied to the accumulators: not ahead of the MFMAs
     const f32x4 q = gate_transpose(acc0 + acc1 + (f32x4){(float)zh[0], (float)zh[1], (float)zh[2], (float)zh[3]});  // i, j, f, o of (row, unit)
     const bool act = s < lenr;
     const float cn = fmaf(fast_sigmoid(q[2]), c, fast_sigmoid(q[0]) * fast_tanh(q[1]));
