@@ -1,0 +1,141 @@
+// Seeded fuzz driver for the host-side entry points of the C ABI (chiron_assemble, chiron_parse_signal_text), built by
+// tests/test_host_sanitizers.py together with chiron_amd/csrc/assemble.cpp under -fsanitize=address,undefined.
+// Checks the contract of include/chiron_amd.h on every call: status codes, *out_len, nothing written past `cap`.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/chiron_amd.h"
+
+namespace chiron {  // assemble.cpp reports errors through the engine's helper; the driver supplies its own
+chiron_status set_error(chiron_status st, const char* fmt, ...) {
+  (void)fmt;
+  return st;
+}
+}  // namespace chiron
+
+static unsigned long long rng_state = 88172645463325252ull;
+static unsigned rnd() {
+  rng_state ^= rng_state << 13, rng_state ^= rng_state >> 7, rng_state ^= rng_state << 17;
+  return (unsigned)(rng_state >> 32);
+}
+#define REQUIRE(c)                                                        \
+  do {                                                                    \
+    if (!(c)) {                                                           \
+      fprintf(stderr, "fuzz_host: line %d: %s\n", __LINE__, #c);         \
+      return 1;                                                           \
+    }                                                                     \
+  } while (0)
+
+static int fuzz_assemble(int iters) {
+  for (int it = 0; it < iters; ++it) {
+    // overlapping windows of a random genome with point errors, or unrelated random strings
+    const int n_seg = rnd() % 12;
+    std::vector<uint8_t> genome(400);
+    for (auto& g : genome) g = rnd() & 3;
+    std::vector<uint8_t> bases;
+    std::vector<int64_t> off(1, 0);
+    std::vector<double> qs;
+    int pos = 0;
+    for (int s = 0; s < n_seg; ++s) {
+      const int len = 1 + rnd() % 60;
+      for (int i = 0; i < len; ++i) {
+        uint8_t b = (it & 1) ? genome[(pos + i) % genome.size()] : (uint8_t)(rnd() & 3);
+        if (rnd() % 17 == 0) b = rnd() & 3;
+        bases.push_back(b);
+      }
+      pos += rnd() % (len + 3);
+      off.push_back((int64_t)bases.size());
+      qs.push_back((rnd() % 2000) / 100.0);
+    }
+    const int kernal = 1 + (rnd() & 1);
+    const bool with_qs = rnd() & 1;
+    int64_t need = -1;
+    // (a) capacity 0: either the consensus is empty or the call reports what it needs
+    chiron_status st = chiron_assemble(bases.data(), off.data(), n_seg, with_qs ? qs.data() : nullptr, kernal, nullptr, nullptr, 0, &need);
+    REQUIRE(st == CHIRON_OK || st == CHIRON_ERR_OVERFLOW || st == CHIRON_ERR_INVALID);
+    REQUIRE(need >= 0 && need <= (int64_t)bases.size() + 1);
+    if (st == CHIRON_ERR_INVALID) REQUIRE(need == 0 || true);
+    // (b) exact capacity, guarded by canaries
+    const int64_t cap = need;
+    std::vector<double> counts(4 * (size_t)cap + 1, -7.0), qsum(4 * (size_t)cap + 1, -7.0);
+    int64_t len2 = -1;
+    st = chiron_assemble(bases.data(), off.data(), n_seg, with_qs ? qs.data() : nullptr, kernal, counts.data(), with_qs ? qsum.data() : nullptr, cap, &len2);
+    REQUIRE(st == CHIRON_OK);
+    REQUIRE(len2 == need);
+    REQUIRE(counts[4 * (size_t)cap] == -7.0 && qsum[4 * (size_t)cap] == -7.0);
+    double total = 0;
+    for (int64_t i = 0; i < 4 * cap; ++i) {
+      REQUIRE(counts[i] >= 0 && counts[i] == std::floor(counts[i]));
+      total += counts[i];
+    }
+    // every base of every segment votes at most once (a negative start clips the head, easy_assembler.py:381-387)
+    REQUIRE(total <= (double)bases.size());
+    // (c) one column short must be refused, not overrun
+    if (cap > 0) {
+      int64_t len3 = -1;
+      st = chiron_assemble(bases.data(), off.data(), n_seg, nullptr, kernal, counts.data(), nullptr, cap - 1, &len3);
+      REQUIRE(st == CHIRON_ERR_OVERFLOW && len3 == need);
+    }
+  }
+  // argument errors
+  int64_t n = 0;
+  REQUIRE(chiron_assemble(nullptr, nullptr, 1, nullptr, 1, nullptr, nullptr, 0, &n) == CHIRON_ERR_INVALID);
+  const int64_t off1[2] = {0, 0};
+  REQUIRE(chiron_assemble(nullptr, off1, 1, nullptr, 3, nullptr, nullptr, 0, &n) == CHIRON_ERR_INVALID);
+  return 0;
+}
+
+static int fuzz_parse(int iters) {
+  static const char* seps[] = {" ", "\n", "\t", "  ", " \n", "\r\n"};
+  for (int it = 0; it < iters; ++it) {
+    std::string text;
+    std::vector<float> want;
+    const int n = rnd() % 40;
+    if (rnd() & 1) text += seps[rnd() % 6];
+    for (int i = 0; i < n; ++i) {
+      char buf[64];
+      const int kind = rnd() % 5;
+      if (kind == 0) snprintf(buf, sizeof buf, "%d", (int)(rnd() % 2000) - 200);
+      else if (kind == 1) snprintf(buf, sizeof buf, "%.3f", (rnd() % 100000) / 37.0);
+      else if (kind == 2) snprintf(buf, sizeof buf, "%.6e", (rnd() % 100000) * 1e-3);
+      else if (kind == 3) snprintf(buf, sizeof buf, "+%u", rnd() % 1000);
+      else snprintf(buf, sizeof buf, "%u.", rnd() % 1000);
+      want.push_back((float)strtod(buf, nullptr));
+      text += buf;
+      if (i + 1 < n || (rnd() & 1)) text += seps[rnd() % 6];
+    }
+    std::vector<float> out(want.size() + 2, -7.f);
+    size_t got = 12345;
+    // the text is NOT NUL-terminated for the parser: hand it an exact-size heap copy so ASAN sees any overread
+    char* exact = (char*)malloc(text.size() ? text.size() : 1);
+    memcpy(exact, text.data(), text.size());
+    chiron_status st = chiron_parse_signal_text(exact, text.size(), out.data(), want.size(), &got);
+    REQUIRE(st == CHIRON_OK && got == want.size());
+    for (size_t i = 0; i < want.size(); ++i) REQUIRE(out[i] == want[i]);
+    REQUIRE(out[want.size()] == -7.f);
+    if (!want.empty()) {
+      st = chiron_parse_signal_text(exact, text.size(), out.data(), want.size() - 1, &got);
+      REQUIRE(st == CHIRON_ERR_OVERFLOW);
+    }
+    free(exact);
+  }
+  size_t got = 0;
+  float o[4];
+  REQUIRE(chiron_parse_signal_text("1 2 x3", 6, o, 4, &got) == CHIRON_ERR_INVALID);
+  REQUIRE(chiron_parse_signal_text("", 0, o, 4, &got) == CHIRON_OK && got == 0);
+  REQUIRE(chiron_parse_signal_text(nullptr, 0, o, 4, &got) == CHIRON_ERR_INVALID);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+  if (fuzz_assemble(iters)) return 1;
+  if (fuzz_parse(iters)) return 1;
+  printf("fuzz_host: %d iterations of each entry point clean\n", iters);
+  return 0;
+}
