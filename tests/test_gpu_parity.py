@@ -166,6 +166,60 @@ def test_full_batch_1100_properties(dna):
     assert np.abs(res.logits[rows] - cref).max() < TOL
 
 
+def test_producer_and_consumer_threads_share_one_engine(dna):
+    """SURVEY 8b threading contract (chiron_eval.py:369-372: a feeder thread enqueues, the main thread dequeues): one
+    thread submits batches round-robin over the slots while another collects them; every result equals the
+    single-threaded answer, also with a mix of greedy and beam-search batches and of batch sizes."""
+    import queue
+    import threading
+    spec, w = dna
+    L, n_slots, n_batches = 400, 3, 14
+    rng = np.random.RandomState(5)
+    work = []
+    for i in range(n_batches):
+        B = int(rng.choice([1, 7, 32, 64]))
+        x, ln = _windows(390 * (B - 1) + int(rng.randint(1, 400)), L, 390, seed=300 + i)
+        work.append((x, ln, 5 if i % 4 == 3 else 0))
+    with ca.Engine(spec, w, max_batch=64, segment_len=L, n_slots=n_slots, max_beam=5) as eng:
+        ref = [eng.infer(x, ca.seq_len_for_engine(ln, eng.ratio), beam_width=bw, want_logits=True) for x, ln, bw in work]
+        free, busy, got, errs = queue.Queue(), queue.Queue(), {}, []
+        for s in range(n_slots):
+            free.put(s)
+
+        def producer():
+            try:
+                for i, (x, ln, bw) in enumerate(work):
+                    slot = free.get(timeout=60)
+                    eng.submit(slot, x, ca.seq_len_for_engine(ln, eng.ratio), beam_width=bw, want_logits=True)
+                    busy.put((i, slot))
+                busy.put(None)
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+                busy.put(None)
+
+        def consumer():
+            try:
+                while True:
+                    item = busy.get(timeout=60)
+                    if item is None:
+                        return
+                    i, slot = item
+                    got[i] = eng.collect(slot)
+                    free.put(slot)
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        tp, tc = threading.Thread(target=producer), threading.Thread(target=consumer)
+        tp.start(), tc.start()
+        tp.join(120), tc.join(120)
+        assert not errs and not tp.is_alive() and not tc.is_alive(), errs
+    assert sorted(got) == list(range(n_batches))
+    for i, r in enumerate(ref):
+        assert np.array_equal(got[i].logits, r.logits), i
+        assert np.array_equal(got[i].decoded.indices, r.decoded.indices) and np.array_equal(got[i].decoded.values, r.decoded.values), i
+        assert np.array_equal(got[i].log_prob, r.log_prob), i
+
+
 def test_pipeline_end_to_end_on_example_signal(dna, tmp_path):
     """chiron_eval-equivalent run on the reference's example raw signal (read1, 161 windows) with a batch
     size that forces several batches and a wrap-padded tail; FASTQ/segments/meta are written, and the
