@@ -4,7 +4,8 @@
 // Replaces the tf.nn.conv2d + batch_normalization + relu (+ add) chains of chiron/cnn.py:15-83,
 // :234-262 and the x-part of the LSTMCell MatMul (rnn.py:49-65) of the reference.
 //
-//   block tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves, each wave 64x64 = 2x2 MFMA tiles, persistent
+//   block tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves, each wave 64x64 = 2x2 MFMA tiles (projections on the DMA
+//   kernel: 128 x 160, waves 4 x 1, each 32 x 160 = 1x5 tiles, so that N = 8H = 800 is five whole tiles), persistent
 //   workgroups over XCD-aware tile ids.  K order inside a chunk is permuted (lanes 0-31 take k=8g+j, lanes
 //   32-63 take k=8g+4+j) so every operand fetch is one ds_read_b128 feeding four MFMAs; A and B use the same
 //   permutation.  A is a sequence of K-segments (conv taps / fused inputs): per-row source pointers and
@@ -525,15 +526,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// DMA-staged variant (every launch whose A operand is a tensor in HBM, i.e. all but the lifted conv2b):
-// global_load_lds_dwordx4 copies 16 bytes per lane straight from HBM/L2 into LDS -- no staging
+// DMA-staged variant (every launch whose A operand is a tensor in HBM):
+// buffer_load_dwordx4 ... lds copies 16 bytes per lane straight from HBM/L2 into LDS -- no staging
 // VGPRs, no ds_write, no masking VALU.  That matters more than usual here: v_mfma_f32_* runs at the
 // fp32 VECTOR rate and does not overlap VALU work issued on the same SIMD (tools/ubench), so every
 // VALU instruction in the K loop is paid in matrix-pipe time.
 //   * LDS image: [rows][32 floats] unpadded (the DMA destination must be lane-linear); the 16-byte
 //     k-slot of a row is XOR-swizzled with (row>>1)&7 on the SOURCE side and on the fragment reads, which
 //     makes the ds_read_b128 of 16 different rows conflict-free.
-//   * zero padding (conv edges, rows past M, K tails) is a pointer to a zero page instead of a select.
+//   * zero padding (conv edges, rows past M, K tails) is an out-of-range buffer offset (reads zeros) instead of a select.
 //   * one barrier per chunk; the DMA of chunk k+1 is issued right after barrier k and has a whole
 //     chunk of MFMAs to land (hipcc drains vmcnt before the next barrier because an LDS-DMA is pending).
 // ---------------------------------------------------------------------------------------------

@@ -59,7 +59,7 @@ struct GemmParams {
   // output
   float* out;
   int ldo;         // row stride (out_mode 0)
-  int out_mode;    // 0: out[m*ldo + n];  1: LSTM z fragment layout (see lstm.hip)
+  int out_mode;    // 0: out[m*ldo + n];  1: LSTM z layout [t][4-row group][dir][col][4 rows] (see lstm.hip)
   int z_cols;      // out_mode 1: z columns per direction (4*H, TF gate-major order i, j, f, o)
   int z_ndir;      // out_mode 1: directions interleaved in N (N = z_ndir * z_cols)
   int z_dir0;      // out_mode 1: first direction index written by this launch
