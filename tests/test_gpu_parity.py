@@ -164,6 +164,24 @@ def test_full_batch_1100_properties(dna):
     rows = np.concatenate([np.arange(0, B, 37), [B - 1]])
     cref = c_oracle.forward(x[rows], sl[rows], spec.to_dict(), spec.pack(w), 400)
     assert np.abs(res.logits[rows] - cref).max() < TOL
+    # (e) the same batch with 200 rows cut to random lengths (ragged 4-row groups take the per-row store path of the
+    #     projection epilogue and the per-row masking of the recurrence): sampled rows against the oracle, and rows that
+    #     kept their length are bit-identical to (d)'s run
+    rng = np.random.RandomState(3)
+    ln2, x2 = ln.copy(), x.copy()
+    cut = rng.choice(B, 200, replace=False)
+    ln2[cut] = rng.randint(1, L + 1, size=200)
+    for b in cut:
+        x2[b, ln2[b]:] = 0
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=1) as eng:
+        sl2 = ca.seq_len_for_engine(ln2, eng.ratio)
+        r2 = eng.infer(x2, sl2, want_prob=True, want_logits=True)
+    _check_decode(r2, r2.logits, sl2, B)
+    rows2 = np.unique(np.concatenate([cut[:24], rows]))
+    cref2 = c_oracle.forward(x2[rows2], sl2[rows2], spec.to_dict(), spec.pack(w), 400)
+    assert np.abs(r2.logits[rows2] - cref2).max() < TOL
+    same = np.setdiff1d(np.arange(B), cut)
+    assert np.array_equal(r2.logits[same], res.logits[same])
 
 
 def test_producer_and_consumer_threads_share_one_engine(dna):
