@@ -261,3 +261,52 @@ def test_native_signal_text_parser_equals_numpy(built, tmp_path):
     out = np.empty(2, np.float32)
     n = C.c_size_t()
     assert lib.chiron_parse_signal_text(b"1 2 3", 5, out.ctypes.data_as(C.c_void_p), 2, C.byref(n)) == _lib.ERR_OVERFLOW
+
+
+def test_packer_collector_round_trip_random_streams():
+    """Property (rows H5 + P1, chiron_eval.py:321-360 / :403-446): for random reads, batch sizes and drain orders every
+    window comes back exactly once, in within-file order, under its own read; rows whose decode is empty vanish;
+    wrap-padding rows of the last batch are never attributed to a read."""
+    from chiron_amd.engine import DecodeResult, SparseTensor
+    rng = np.random.RandomState(77)
+    for trial in range(60):
+        B = int(rng.choice([1, 2, 3, 4, 7, 16]))
+        L = 3
+        reads = [("r%02d" % i, int(rng.randint(1, 20))) for i in range(int(rng.randint(1, 9)))]
+        packer, col = ce.BatchPacker(B, L, 1.0), ce.ReadCollector()
+        batches, token = [], {}
+        uid = 0
+        for name, n in reads:
+            ev = np.zeros((n, L), dtype=np.float32)
+            for k in range(n):
+                ev[k, 0] = uid      # a unique id per window travels in the signal
+                token[uid] = (name, k)
+                uid += 1
+            col.expect(name, n, (0.0, 0.0))
+            batches += list(packer.add_read(name, ev, np.full(n, L, dtype=np.int32)))
+        last = packer.flush()
+        if last is not None:
+            batches.append(last)
+        assert sum(b.n_valid for b in batches) == uid and all(b.x.shape == (B, L) for b in batches)
+        # "decode": window uid -> (uid % 3) labels (so every third window decodes to nothing), qs = uid
+        order = rng.permutation(len(batches))
+        done = []
+        for bi in order:
+            b = batches[bi]
+            ind, val = [], []
+            for r in range(B):
+                u = int(b.x[r, 0])
+                for p in range(u % 3):
+                    ind.append([r, p])
+                    val.append((u + p) % 4)
+            st = SparseTensor(np.asarray(ind, dtype=np.int64).reshape(-1, 2), np.asarray(val, dtype=np.int64), np.asarray([B, 2]))
+            res = DecodeResult(st, np.zeros((B, 1), np.float32), b.x[:, :1].copy(), None)
+            done += col.add_batch(b, res, True)
+        assert sorted(d[0] for d in done) == sorted(n for n, _ in reads)
+        for name, out_reads, qs_list, meta in done:
+            n = dict(reads)[name]
+            want = [u for u, (nm, k) in sorted(token.items(), key=lambda kv: kv[1][1]) if nm == name and u % 3 > 0]
+            assert len(out_reads) == len(want), (trial, name)
+            assert qs_list.ravel().tolist() == [float(u) for u in want]
+            for rd, u in zip(out_reads, want):
+                assert [int(v) for v in rd] == [(u + p) % 4 for p in range(u % 3)]
