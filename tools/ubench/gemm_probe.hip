@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     g.M = (int)M;
     g.T_out = T;
     g.nseg = ntap;
-    for (int j = 0; j < ntap; ++j) g.seg[j] = GemmSeg{act, LD, 0, C, C, T, 1, j - ntap / 2, 0};
+    for (int j = 0; j < ntap; ++j) g.seg[j] = GemmSeg{act, LD, 0, C, C, T, 1, getenv("PROBE_SHIFT0") ? 0 : j - ntap / 2, 0};  // PROBE_SHIFT0: every tap reads the same rows
     g.relu = 1;
     g.out = out;
     g.ldo = LD;
