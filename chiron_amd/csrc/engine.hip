@@ -3,6 +3,7 @@
 // sub-graph (chiron_eval.py:465-492) of the reference.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -131,6 +132,9 @@ struct BlockPlan {
   int t_in = 0, t_out = 0;
   float *lift_a = nullptr, *lift_b = nullptr;  // lift: conv2a folded scale/shift
   float* res_a = nullptr;                      // lift: branch1 folded scale
+  // lift, population BN: conv2a + conv2b as a piecewise-linear table of the signal value (pwl.hip)
+  float *pwl_bp = nullptr, *pwl_tab = nullptr, *pwl_shift = nullptr;
+  int pwl_nbp = 0;
   ConvGemmPlan ga, gb, gc;                     // conv2a (non-lift), conv2b, conv2c(+conv1)
   // bn_mode = batch (cnn.py:166-188): the GEMM weights above are raw, gc holds conv2c alone, g1 the 1x1 branch1 conv;
   // scale / offset of the four BN sites (conv1 only when i_bn)
@@ -384,6 +388,44 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       if ((st = dev_upload(e, &bp.lift_a, la))) return st;
       if ((st = dev_upload(e, &bp.lift_b, lb))) return st;
       if ((st = dev_upload(e, &bp.res_a, ra))) return st;
+      if (!batch && getenv("CHIRON_NO_PWL") == nullptr) {
+        // f[tap][n](s) = sum_c W2b'[tap][c][n] * relu(s*a[c] + b[c]) is piecewise linear in the signal value s:
+        // tabulate (alpha, beta) per interval between consecutive breakpoints -b[c]/a[c] (pwl.hip).  float64 sums.
+        std::vector<std::pair<double, int>> brk;  // (breakpoint, channel)
+        for (int c = 0; c < co; ++c)
+          if (la[c] != 0.f) brk.emplace_back(-(double)lb[c] / (double)la[c], c);
+        std::sort(brk.begin(), brk.end());
+        const int nb = (int)brk.size(), kk = b.k;
+        std::vector<double> al((size_t)kk * co, 0.0), be((size_t)kk * co, 0.0);
+        auto toggle = [&](int c, double sign) {
+          for (int tap = 0; tap < kk; ++tap)
+            for (int n = 0; n < co; ++n) {
+              const double wv = (double)(W2b[((size_t)tap * co + c) * co + n] * f2b.inv[n]) * sign;
+              al[(size_t)tap * co + n] += wv * (double)la[c];
+              be[(size_t)tap * co + n] += wv * (double)lb[c];
+            }
+        };
+        // s -> -inf: a channel is active iff a < 0, or a == 0 and b > 0
+        for (int c = 0; c < co; ++c)
+          if (la[c] < 0.f || (la[c] == 0.f && lb[c] > 0.f)) toggle(c, 1.0);
+        std::vector<float> tab((size_t)(nb + 1) * kk * co * 2), bpf(std::max(nb, 1), 0.f);
+        for (int iv = 0; iv <= nb; ++iv) {
+          if (iv > 0) {
+            const int c = brk[iv - 1].second;
+            toggle(c, la[c] > 0.f ? 1.0 : -1.0);  // crossing its breakpoint upwards switches a channel on (a > 0) or off (a < 0)
+            bpf[iv - 1] = (float)brk[iv - 1].first;
+          }
+          for (size_t i = 0; i < (size_t)kk * co; ++i) {
+            tab[((size_t)iv * kk * co + i) * 2] = (float)al[i];
+            tab[((size_t)iv * kk * co + i) * 2 + 1] = (float)be[i];
+          }
+        }
+        std::vector<float> sh2(f2b.sh.begin(), f2b.sh.begin() + co);
+        bp.pwl_nbp = nb;
+        if ((st = dev_upload(e, &bp.pwl_bp, bpf))) return st;
+        if ((st = dev_upload(e, &bp.pwl_tab, tab))) return st;
+        if ((st = dev_upload(e, &bp.pwl_shift, sh2))) return st;
+      }
       // conv2c with the branch1 shift folded into the epilogue shift
       const int K = cop;
       std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
@@ -815,7 +857,17 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.relu = 1;
       g.out = bufB;
       g.ldo = b.c;
-      {
+      bool done_pwl = false;
+      if (b.pwl_tab != nullptr) {
+        // conv2a + conv2b in one memory-bound pass over a piecewise-linear table of the signal value (pwl.hip)
+        PwlConvParams q;
+        q.sig = sig, q.bp = b.pwl_bp, q.tab = reinterpret_cast<const float2*>(b.pwl_tab), q.shift = b.pwl_shift, q.out = bufB;
+        q.B = B, q.L = e->L, q.T_out = b.t_out, q.k = b.k, q.stride = b.stride, q.left = b.left, q.C = b.c, q.nbp = b.pwl_nbp;
+        q.fmt = e->f16 ? 1 : e->split ? 2 : 0;
+        Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_out * (double)b.k * b.c, 4.0 * B * e->L + (e->f16 ? 2.0 : 4.0) * B * b.t_out * b.c);
+        done_pwl = launch_pwl_conv(q, s->stream);
+      }
+      if (!done_pwl) {
         // conv2a of the signal is materialised (one HBM-bound pass), conv2b is then an ordinary DMA launch
         {
           Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_in * b.c, 4.0 * B * b.t_in + (e->f16 ? 2.0 : 4.0) * B * b.t_in * b.c);

@@ -104,6 +104,18 @@ void launch_stem_conv(const float* sig, const float* w, const float* shift, void
 // half > 0: the row is two halves of `half` columns (fw | bw) and the second one starts at column half_dst of the
 // destination (a 32-element block boundary), so that each direction can be read as a K-segment of its own.
 void launch_split_convert(const float* src, void* dst, long rows, int cols, int ld, int half, int half_dst, hipStream_t stream);
+// res_layer1 conv2a + conv2b as a piecewise-linear table (pwl.hip)
+struct PwlConvParams {
+  const float* sig;   // [B][L]
+  const float* bp;    // [nbp] breakpoints of relu(s*a[c] + b[c]), ascending
+  const float2* tab;  // [nbp + 1][k][C] (alpha, beta): f[tap][n](s) = alpha*s + beta on the interval
+  const float* shift; // [C] folded BN offset of conv2b
+  void* out;          // [B*T_out][C] in the engine's activation format
+  int B, L, T_out, k, stride, left, C, nbp;
+  int fmt;            // 0 fp32, 1 halves, 2 split
+};
+bool launch_pwl_conv(const PwlConvParams& p, hipStream_t stream);
+
 void launch_lift(const float* sig, const float* a, const float* b, void* out, long n_pos, int C, int fmt /* 0 fp32, 1 halves, 2 split */,
                  hipStream_t stream);
 

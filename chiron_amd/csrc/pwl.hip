@@ -1,0 +1,93 @@
+// res_layer1 / branch2 up to conv2b as ONE memory-bound pass for gfx950 (population BN).
+//
+// The first residual block sees a ONE-channel input (cnn.py:380-389 DNA_model1, :234-262 residual_layer): conv2a is
+// a 1x1 convolution of the raw signal, so with BN folded its output is a1[pos][c] = relu(s[pos]*a[c] + b[c]) -- every
+// one of the 256 channels is a function of the single scalar s[pos].  conv2b (1 x k over a1, BN, ReLU) is therefore
+//     y[pos][n] = relu( sh[n] + sum_tap f[tap][n]( s[pos*stride + tap - left] ) ),
+//     f[tap][n](s) = sum_c W2b'[tap][c][n] * relu(s*a[c] + b[c]),
+// and each f is PIECEWISE LINEAR in s with at most C breakpoints s_c = -b[c]/a[c] (the same for every tap and n).
+// The engine tabulates, on the host and in float64, alpha and beta of f = alpha*s + beta for every interval between
+// consecutive breakpoints; this kernel finds the interval of each sample (binary search in LDS) and evaluates k taps
+// with one 8-byte table read each -- instead of materialising a1 (450 MB) and running a K = k*256 GEMM over it
+// (173 GFLOP per batch for DNA_default).  Same function, re-associated: the table sums in float64, the result differs
+// from the GEMM form by fp32 rounding only (tests/test_gpu_parity.py holds the 1e-4 logit bound against the oracle).
+#include "kernels.h"
+
+namespace chiron {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PWL_TP = 32;        // output positions per workgroup
+constexpr int PWL_MAX_BP = 512;   // breakpoints (= channels of conv2a) held in LDS
+constexpr int PWL_MAX_S = 512;    // samples a workgroup looks at: (PWL_TP - 1) * stride + k
+
+template <int FMT>
+__global__ __launch_bounds__(256) void pwl_conv_kernel(const PwlConvParams p) {
+  __shared__ float bps[PWL_MAX_BP];
+  __shared__ float ss[PWL_MAX_S];
+  __shared__ int ks[PWL_MAX_S];
+  const int tid = threadIdx.x;
+  const int tiles_per_row = (p.T_out + PWL_TP - 1) / PWL_TP;
+  const int b = blockIdx.x / tiles_per_row;
+  const int t0 = (blockIdx.x - b * tiles_per_row) * PWL_TP;
+  const int np = min(PWL_TP, p.T_out - t0);
+  for (int i = tid; i < p.nbp; i += 256) bps[i] = p.bp[i];
+  __syncthreads();
+  const int nsamp = (np - 1) * p.stride + p.k;
+  for (int i = tid; i < nsamp; i += 256) {
+    const int idx = t0 * p.stride - p.left + i;
+    const bool valid = idx >= 0 && idx < p.L;  // SAME padding pads a1 with zeros: such taps contribute nothing
+    const float s = valid ? p.sig[(long)b * p.L + idx] : 0.f;
+    int lo = 0, hi = p.nbp;  // interval = number of breakpoints below s
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (bps[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    ss[i] = s;
+    ks[i] = valid ? lo : -1;
+  }
+  __syncthreads();
+  const int C = p.C, k = p.k;
+  for (int n = tid; n < C; n += 256) {
+    const float sh = p.shift[n];
+    const float2* tab = p.tab + n;
+    for (int pp = 0; pp < np; ++pp) {
+      float acc = sh;
+      for (int tap = 0; tap < k; ++tap) {
+        const int i = pp * p.stride + tap;
+        const int kk = ks[i];
+        if (kk >= 0) {
+          const float2 ab = tab[((long)kk * k + tap) * C];
+          acc += fmaf(ab.x, ss[i], ab.y);
+        }
+      }
+      const float y = fmaxf(acc, 0.f);
+      const long pos = (long)b * p.T_out + t0 + pp;
+      if (FMT == 0) {
+        reinterpret_cast<float*>(p.out)[pos * C + n] = y;
+      } else if (FMT == 1) {
+        reinterpret_cast<_Float16*>(p.out)[pos * C + n] = (_Float16)y;
+      } else {  // split: per 32-element block 32 hi halves, then 32 lo halves
+        const _Float16 hi = (_Float16)y;
+        _Float16* o = reinterpret_cast<_Float16*>(p.out) + (pos * C + (n >> 5) * 32) * 2 + (n & 31);
+        o[0] = hi;
+        o[32] = (_Float16)(y - (float)hi);
+      }
+    }
+  }
+}
+
+bool launch_pwl_conv(const PwlConvParams& p, hipStream_t stream) {
+  if (p.nbp > PWL_MAX_BP || (PWL_TP - 1) * p.stride + p.k > PWL_MAX_S) return false;
+  const int tiles_per_row = (p.T_out + PWL_TP - 1) / PWL_TP;
+  const dim3 grid(p.B * tiles_per_row), block(256);
+  if (p.fmt == 0)
+    hipLaunchKernelGGL(pwl_conv_kernel<0>, grid, block, 0, stream, p);
+  else if (p.fmt == 1)
+    hipLaunchKernelGGL(pwl_conv_kernel<1>, grid, block, 0, stream, p);
+  else
+    hipLaunchKernelGGL(pwl_conv_kernel<2>, grid, block, 0, stream, p);
+  return true;
+}
+
+}  // namespace chiron
