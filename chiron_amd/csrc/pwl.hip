@@ -47,38 +47,56 @@ __global__ __launch_bounds__(256) void pwl_conv_kernel(const PwlConvParams p) {
     ks[i] = valid ? lo : -1;
   }
   __syncthreads();
+  // thread = (position mod 4, four adjacent channels): two 16-byte table reads cover (alpha, beta) of four channels
   const int C = p.C, k = p.k;
-  for (int n = tid; n < C; n += 256) {
-    const float sh = p.shift[n];
-    const float2* tab = p.tab + n;
-    for (int pp = 0; pp < np; ++pp) {
-      float acc = sh;
+  const int par = tid >> 6, t4 = tid & 63;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  for (int n = 4 * t4; n < C; n += 256) {
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    const float* tab = reinterpret_cast<const float*>(p.tab + n);
+    for (int pp = par; pp < np; pp += 4) {
+      f32x4 acc = sh;
       for (int tap = 0; tap < k; ++tap) {
         const int i = pp * p.stride + tap;
         const int kk = ks[i];
         if (kk >= 0) {
-          const float2 ab = tab[((long)kk * k + tap) * C];
-          acc += fmaf(ab.x, ss[i], ab.y);
+          const float* q = tab + ((long)kk * k + tap) * C * 2;
+          const f32x4 ab0 = *reinterpret_cast<const f32x4*>(q), ab1 = *reinterpret_cast<const f32x4*>(q + 4);
+          const float sv = ss[i];
+          acc[0] += fmaf(ab0[0], sv, ab0[1]);
+          acc[1] += fmaf(ab0[2], sv, ab0[3]);
+          acc[2] += fmaf(ab1[0], sv, ab1[1]);
+          acc[3] += fmaf(ab1[2], sv, ab1[3]);
         }
       }
-      const float y = fmaxf(acc, 0.f);
+      f32x4 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = fmaxf(acc[j], 0.f);
       const long pos = (long)b * p.T_out + t0 + pp;
       if (FMT == 0) {
-        reinterpret_cast<float*>(p.out)[pos * C + n] = y;
-      } else if (FMT == 1) {
-        reinterpret_cast<_Float16*>(p.out)[pos * C + n] = (_Float16)y;
-      } else {  // split: per 32-element block 32 hi halves, then 32 lo halves
-        const _Float16 hi = (_Float16)y;
-        _Float16* o = reinterpret_cast<_Float16*>(p.out) + (pos * C + (n >> 5) * 32) * 2 + (n & 31);
-        o[0] = hi;
-        o[32] = (_Float16)(y - (float)hi);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + pos * C + n) = y;
+      } else {
+        f16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hi[j] = (_Float16)y[j];
+          lo[j] = (_Float16)(y[j] - (float)hi[j]);
+        }
+        if (FMT == 1) {
+          *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(p.out) + pos * C + n) = hi;
+        } else {  // split: per 32-element block 32 hi halves, then 32 lo halves
+          _Float16* o = reinterpret_cast<_Float16*>(p.out) + (pos * C + (n >> 5) * 32) * 2 + (n & 31);
+          *reinterpret_cast<f16x4*>(o) = hi;
+          *reinterpret_cast<f16x4*>(o + 32) = lo;
+        }
       }
     }
   }
 }
 
 bool launch_pwl_conv(const PwlConvParams& p, hipStream_t stream) {
-  if (p.nbp > PWL_MAX_BP || (PWL_TP - 1) * p.stride + p.k > PWL_MAX_S) return false;
+  if (p.nbp > PWL_MAX_BP || (PWL_TP - 1) * p.stride + p.k > PWL_MAX_S || (p.C & 3)) return false;
   const int tiles_per_row = (p.T_out + PWL_TP - 1) / PWL_TP;
   const dim3 grid(p.B * tiles_per_row), block(256);
   if (p.fmt == 0)
