@@ -415,9 +415,12 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
             toggle(c, la[c] > 0.f ? 1.0 : -1.0);  // crossing its breakpoint upwards switches a channel on (a > 0) or off (a < 0)
             bpf[iv - 1] = (float)brk[iv - 1].first;
           }
+          // value at the interval's reference point (its lower breakpoint; the first breakpoint for the interval below it)
+          // instead of the intercept: alpha*(s - ref) + f(ref) has no cancellation between alpha*s and beta
+          const double ref = nb > 0 ? (double)(float)brk[std::max(iv - 1, 0)].first : 0.0;
           for (size_t i = 0; i < (size_t)kk * co; ++i) {
             tab[((size_t)iv * kk * co + i) * 2] = (float)al[i];
-            tab[((size_t)iv * kk * co + i) * 2 + 1] = (float)be[i];
+            tab[((size_t)iv * kk * co + i) * 2 + 1] = (float)(al[i] * ref + be[i]);
           }
         }
         std::vector<float> sh2(f2b.sh.begin(), f2b.sh.begin() + co);
@@ -658,7 +661,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     chiron_engine_destroy(e);
     return st;
   }
-  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res"};
+  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res", "conv1_pwl"};
   *out = e;
   return CHIRON_OK;
 }
@@ -691,7 +694,7 @@ extern "C" chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out
 // ----------------------------------------------------------------------------------------------
 // launch sequence
 // ----------------------------------------------------------------------------------------------
-enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES };
+enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES, PN_PWL };
 
 struct Prof {
   chiron_engine* e;
@@ -864,7 +867,7 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
         q.sig = sig, q.bp = b.pwl_bp, q.tab = reinterpret_cast<const float2*>(b.pwl_tab), q.shift = b.pwl_shift, q.out = bufB;
         q.B = B, q.L = e->L, q.T_out = b.t_out, q.k = b.k, q.stride = b.stride, q.left = b.left, q.C = b.c, q.nbp = b.pwl_nbp;
         q.fmt = e->f16 ? 1 : e->split ? 2 : 0;
-        Prof pr(e, s, PN_LIFT, 2.0 * B * b.t_out * (double)b.k * b.c, 4.0 * B * e->L + (e->f16 ? 2.0 : 4.0) * B * b.t_out * b.c);
+        Prof pr(e, s, PN_PWL, 2.0 * B * b.t_out * (double)b.k * b.c, 4.0 * B * e->L + (e->f16 ? 2.0 : 4.0) * B * b.t_out * b.c);
         done_pwl = launch_pwl_conv(q, s->stream);
       }
       if (!done_pwl) {

@@ -108,7 +108,7 @@ void launch_split_convert(const float* src, void* dst, long rows, int cols, int 
 struct PwlConvParams {
   const float* sig;   // [B][L]
   const float* bp;    // [nbp] breakpoints of relu(s*a[c] + b[c]), ascending
-  const float2* tab;  // [nbp + 1][k][C] (alpha, beta): f[tap][n](s) = alpha*s + beta on the interval
+  const float2* tab;  // [nbp + 1][k][C] (alpha, f(ref)): f[tap][n](s) = alpha*(s - ref) + f(ref) on the interval, ref = its lower breakpoint
   const float* shift; // [C] folded BN offset of conv2b
   void* out;          // [B*T_out][C] in the engine's activation format
   int B, L, T_out, k, stride, left, C, nbp;

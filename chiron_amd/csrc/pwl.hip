@@ -6,8 +6,8 @@
 //     y[pos][n] = relu( sh[n] + sum_tap f[tap][n]( s[pos*stride + tap - left] ) ),
 //     f[tap][n](s) = sum_c W2b'[tap][c][n] * relu(s*a[c] + b[c]),
 // and each f is PIECEWISE LINEAR in s with at most C breakpoints s_c = -b[c]/a[c] (the same for every tap and n).
-// The engine tabulates, on the host and in float64, alpha and beta of f = alpha*s + beta for every interval between
-// consecutive breakpoints; this kernel finds the interval of each sample (binary search in LDS) and evaluates k taps
+// The engine tabulates, on the host and in float64, the slope alpha and the value f(ref) at the lower breakpoint ref of
+// every interval between consecutive breakpoints (f = alpha*(s - ref) + f(ref): no cancellation); this kernel finds the interval of each sample (binary search in LDS) and evaluates k taps
 // with one 8-byte table read each -- instead of materialising a1 (450 MB) and running a K = k*256 GEMM over it
 // (173 GFLOP per batch for DNA_default).  Same function, re-associated: the table sums in float64, the result differs
 // from the GEMM form by fp32 rounding only (tests/test_gpu_parity.py holds the 1e-4 logit bound against the oracle).
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void pwl_conv_kernel(const PwlConvParams p) {
       const int mid = (lo + hi) >> 1;
       if (bps[mid] < s) lo = mid + 1; else hi = mid;
     }
-    ss[i] = s;
+    // the table holds f at the interval's reference point (its lower breakpoint; the first one for interval 0)
+    ss[i] = s - (p.nbp > 0 ? bps[max(lo - 1, 0)] : 0.f);
     ks[i] = valid ? lo : -1;
   }
   __syncthreads();

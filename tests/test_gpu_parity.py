@@ -184,6 +184,35 @@ def test_full_batch_1100_properties(dna):
     assert np.array_equal(r2.logits[same], res.logits[same])
 
 
+def test_first_conv_table_form_equals_gemm_form(dna, rna, monkeypatch):
+    """res_layer1's conv2a + conv2b run as a piecewise-linear table of the signal value (pwl.hip).  CHIRON_NO_PWL=1
+    makes the engine materialise conv2a and run conv2b as a GEMM instead: the same function, re-associated -- both
+    forms sit within the oracle bound and within fp32 rounding of each other, for k = 3 / stride 1 (DNA) and k = 13 /
+    stride 5 (RNA), including signal values outside every breakpoint, exact zeros and windows cut short."""
+    from oracle import c_oracle
+    for (spec, w), L, jump in ((dna, 400, 390), (rna, 500, 490)):
+        B = 24
+        x, ln = _windows(jump * (B - 1) + 137, L, jump, seed=71)
+        x = x.copy()
+        x[0, :50] = 0.0          # zeros
+        x[1, :50] = 5000.0       # above every breakpoint
+        x[2, :50] = -3000.0      # below every breakpoint
+        x[3, ::2] += 0.37        # non-integer samples
+        outs = {}
+        for flag in ("", "1"):
+            if flag:
+                monkeypatch.setenv("CHIRON_NO_PWL", flag)
+            else:
+                monkeypatch.delenv("CHIRON_NO_PWL", raising=False)
+            with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
+                sl = ca.seq_len_for_engine(ln, eng.ratio)
+                outs[flag] = eng.infer(x, sl, want_logits=True).logits
+        monkeypatch.delenv("CHIRON_NO_PWL", raising=False)
+        cref = c_oracle.forward(x, sl, spec.to_dict(), spec.pack(w), spec.output_len(L))
+        assert np.abs(outs[""] - cref).max() < TOL and np.abs(outs["1"] - cref).max() < TOL
+        assert np.abs(outs[""] - outs["1"]).max() < 8e-5   # measured 3e-5 (largest on the rows with out-of-range samples)
+
+
 def test_producer_and_consumer_threads_share_one_engine(dna):
     """SURVEY 8b threading contract (chiron_eval.py:369-372: a feeder thread enqueues, the main thread dequeues): one
     thread submits batches round-robin over the slots while another collects them; every result equals the
