@@ -36,12 +36,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // tools/ubench/mfma4x4_bcast.hip), so a wave reads 2 KB of h per step instead of 25.6 KB.
 constexpr int HG = 16 * 4 * 8;  // floats per group and buffer
 
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
+// Gate math on the hardware exp2 / rcp.  The four pre-activations are scaled two at a time (v_pk_mul_f32) and the
+// "+ 1" of the four denominators added two at a time (v_pk_add_f32): every VALU instruction of the step is paid in
+// matrix-pipe time (tools/ubench/mfma_valu_overlap.hip).
+//   sigmoid(x) = 1 / (1 + 2^(-x log2 e)),  tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1)   (saturates correctly at +-inf)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float fast_tanh(float x) {
-  // 1 - 2/(e^{2x}+1); saturates correctly at +-inf, |abs err| ~1e-7
-  return fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f), 1.0f);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * (2.0f * LOG2E)) + 1.0f), 1.0f);
+}
+// q = (i, j, f, o) pre-activations, c = previous cell state  ->  new cell state; *h_out = new output
+__device__ __forceinline__ float lstm_cell(f32x4 q, float c, float* h_out) {
+  const f32x2 e_if = (f32x2){q[0], q[2]} * (f32x2){-LOG2E, -LOG2E};
+  const f32x2 e_oj = (f32x2){q[3], q[1]} * (f32x2){-LOG2E, 2.0f * LOG2E};
+  const f32x2 d_if = (f32x2){__builtin_amdgcn_exp2f(e_if[0]), __builtin_amdgcn_exp2f(e_if[1])} + (f32x2){1.0f, 1.0f};
+  const f32x2 d_oj = (f32x2){__builtin_amdgcn_exp2f(e_oj[0]), __builtin_amdgcn_exp2f(e_oj[1])} + (f32x2){1.0f, 1.0f};
+  const float si = __builtin_amdgcn_rcpf(d_if[0]), sf = __builtin_amdgcn_rcpf(d_if[1]);
+  const float so = __builtin_amdgcn_rcpf(d_oj[0]);
+  const float tj = fmaf(-2.0f, __builtin_amdgcn_rcpf(d_oj[1]), 1.0f);
+  const float cn = fmaf(sf, c, si * tj);
+  *h_out = so * fast_tanh(cn);
+  return cn;
 }
 
 // 4x4 transpose between the register index and lane bits [5:4], in registers: (lane = gate*16 + unit, reg = row) ->
@@ -164,8 +179,8 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
       const f32x4 q = gate_transpose(acc[g] + z[g]);  // i, j, f, o of (row, unit)
       // rows past their length carry (c, h) and emit zeros (dynamic_rnn); whatever their z slot held is discarded
       const bool act = s < lenr[g];
-      const float cn = fmaf(fast_sigmoid(q[2]), c[g], fast_sigmoid(q[0]) * fast_tanh(q[1]));
-      const float hnew = fast_sigmoid(q[3]) * fast_tanh(cn);
+      float hnew;
+      const float cn = lstm_cell(q, c[g], &hnew);
       c[g] = act ? cn : c[g];
       hprev[g] = act ? hnew : hprev[g];
       if (live) {
@@ -263,8 +278,8 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh), "+v"(acc0), "+v"(acc1));  // tied to the accumulators: not ahead of the MFMAs
     const f32x4 q = gate_transpose(acc0 + acc1 + (f32x4){(float)zh[0], (float)zh[1], (float)zh[2], (float)zh[3]});  // i, j, f, o of (row, unit)
     const bool act = s < lenr;
-    const float cn = fmaf(fast_sigmoid(q[2]), c, fast_sigmoid(q[0]) * fast_tanh(q[1]));
-    const float hnew = fast_sigmoid(q[3]) * fast_tanh(cn);
+    float hnew;
+    const float cn = lstm_cell(q, c, &hnew);
     c = act ? cn : c;
     hprev = act ? hnew : hprev;
     if (live) {
