@@ -213,6 +213,30 @@ def test_first_conv_table_form_equals_gemm_form(dna, rna, monkeypatch):
         assert np.abs(outs[""] - outs["1"]).max() < 8e-5   # measured 3e-5 (largest on the rows with out-of-range samples)
 
 
+def test_first_conv_table_degenerate_channels(dna):
+    """Channels of conv2a whose folded scale is exactly zero have no breakpoint (constant relu(b): on if b > 0), equal
+    breakpoints give zero-width intervals, a tiny scale puts the breakpoint far outside the signal range."""
+    from oracle import c_oracle
+    spec, w0 = dna
+    w = type(w0)((k, v.copy()) for k, v in w0.items())
+    sc, of = w["res_layer1/branch2/conv2a_bn/scale"], w["res_layer1/branch2/conv2a_bn/offset"]
+    cw = w["res_layer1/branch2/conv2a/weights"].reshape(-1)
+    sc[:6] = 0.0                      # a = 0: constant channels
+    of[:3], of[3:6] = 0.7, -0.7       # on / off
+    sc[6:10], cw[6:10] = sc[10], cw[10]   # identical (a, b) pairs -> duplicate breakpoints
+    of[6:10] = of[10]
+    w["res_layer1/branch2/conv2a_bn/pop_mean"][6:10] = w["res_layer1/branch2/conv2a_bn/pop_mean"][10]
+    w["res_layer1/branch2/conv2a_bn/pop_var"][6:10] = w["res_layer1/branch2/conv2a_bn/pop_var"][10]
+    sc[12] = 1e-12                    # breakpoint at ~ +-1e12
+    L, B = 400, 9
+    x, ln = _windows(390 * (B - 1) + 77, L, 390, seed=91)
+    with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
+        sl = ca.seq_len_for_engine(ln, eng.ratio)
+        res = eng.infer(x, sl, want_logits=True)
+    cref = c_oracle.forward(x, sl, spec.to_dict(), spec.pack(w), 400)
+    assert np.isfinite(res.logits).all() and np.abs(res.logits - cref).max() < TOL
+
+
 def test_producer_and_consumer_threads_share_one_engine(dna):
     """SURVEY 8b threading contract (chiron_eval.py:369-372: a feeder thread enqueues, the main thread dequeues): one
     thread submits batches round-robin over the slots while another collects them; every result equals the
