@@ -19,6 +19,7 @@
 //   The prefix trie (parent / label / children / slot / depth) lives in a per-segment slab of HBM with
 //   1 + beam*T nodes (only leaves that survive a frame are materialised).
 #include "kernels.h"
+#include "ctc_math.h"
 
 #include <cstdlib>
 
@@ -35,14 +36,10 @@ struct __attribute__((aligned(32))) BeamNode {
   int depth;  // number of labels on the path from the root
 };
 
-__device__ __forceinline__ float log_sum_exp(float a, float b) {  // ctc_loss_util.h LogSumExp
-  // max + log(1 + exp(min - max)) on the hardware exp2 / log2 (1-2 ulp): the argument of the log lies in (1, 2], so
-  // the absolute error stays at the 1e-7 level of the additions around it.  (The libm-accurate log1pf(expf()) pair was
-  // 300 instructions, two thirds of a frame's work in the register kernel.)
-  const float m = fmaxf(a, b);
-  const float r = m + __logf(1.0f + __expf(fminf(a, b) - m));
-  return (a == NEG_INF) ? b : (b == NEG_INF) ? a : r;
-}
+// ctc_loss_util.h LogSumExp and the per-frame log-softmax run on the operation-exact exp / log pair of ctc_math.h
+// (no libm, no hardware exp2 / log2): the decoder's results are then a pure function of the logits' bits, the same
+// in this kernel, in the sequential kernel below and in the C oracle the tests compare against bit for bit.
+__device__ __forceinline__ float log_sum_exp(float a, float b) { return ctc_log_sum_exp(a, b); }
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -96,14 +93,7 @@ __global__ __launch_bounds__(64) void beam_kernel(const BeamParams p, int node_c
   for (int t = 0; t < len; ++t) {
     // log-softmax of the frame (TF normalises inside Step())
     float logp[CHIRON_KMAX];
-    {
-      float mx = lg[t * K];
-      for (int k = 1; k < K; ++k) mx = fmaxf(mx, lg[t * K + k]);
-      float s = 0.f;
-      for (int k = 0; k < K; ++k) s += expf(lg[t * K + k] - mx);
-      const float lse = logf(s);
-      for (int k = 0; k < K; ++k) logp[k] = (lg[t * K + k] - mx) - lse;
-    }
+    ctc_log_softmax<CHIRON_KMAX>(lg + t * K, logp);   // K == CHIRON_KMAX (checked at launch)
     // ---- P1: carried entries
     for (int i = lane; i < nb; i += 64) {
       const int n = E_node[i];
@@ -374,18 +364,8 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
       const int t = min(t0 + lane, len - 1);
       float x[CHIRON_KMAX];
 #pragma unroll
-      for (int k = 0; k < CHIRON_KMAX; ++k) x[k] = k < K ? lg[t * K + k] : 0.f;
-      float mx = x[0];
-#pragma unroll
-      for (int k = 1; k < CHIRON_KMAX; ++k)
-        if (k < K) mx = fmaxf(mx, x[k]);
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < CHIRON_KMAX; ++k)
-        if (k < K) s += expf(x[k] - mx);
-      const float lse = logf(s);
-#pragma unroll
-      for (int k = 0; k < CHIRON_KMAX; ++k) lpk[k] = (x[k] - mx) - lse;
+      for (int k = 0; k < CHIRON_KMAX; ++k) x[k] = lg[t * K + k];   // K == CHIRON_KMAX (checked at launch)
+      ctc_log_softmax<CHIRON_KMAX>(x, lpk);
     }
     const int tn = min(64, len - t0);
     for (int tt = 0; tt < tn; ++tt) {

@@ -26,7 +26,25 @@ def load():
         _lib.chiron_oracle_beam.restype = C.c_int
         _lib.chiron_oracle_beam.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+        for fn in ("chiron_oracle_ctc_exp", "chiron_oracle_ctc_log"):
+            getattr(_lib, fn).restype = C.c_float
+            getattr(_lib, fn).argtypes = [C.c_float]
+        _lib.chiron_oracle_ctc_lse.restype = C.c_float
+        _lib.chiron_oracle_ctc_lse.argtypes = [C.c_float, C.c_float]
     return _lib
+
+
+def ctc_exp(d):
+    """the decoder's e^d (d <= 0), see chiron_oracle.c exp_neg_"""
+    return float(load().chiron_oracle_ctc_exp(float(d)))
+
+
+def ctc_log(x):
+    return float(load().chiron_oracle_ctc_log(float(x)))
+
+
+def ctc_lse(a, b):
+    return float(load().chiron_oracle_ctc_lse(float(a), float(b)))
 
 
 def _desc(spec):

@@ -280,11 +280,72 @@ typedef struct {
   int in_leaves;
 } bnode;
 
-static float lse2(float a, float b) {
+/* exp / log of the decoder.  TF calls its platform's expf / logf / log1pf here (ctc_loss_util.h LogSumExp,
+ * ctc_beam_search.h Step()), which are not bit-reproducible across libms, and beam search is discontinuous in their
+ * last ulp.  The oracle therefore fixes the pair to a sequence of exactly-specified IEEE operations -- Cody-Waite
+ * range reduction and the Cephes float polynomials, ~1 ulp -- the same sequence the device decoder documents in
+ * chiron_amd/csrc/ctc_math.h (restated here, not included), so that decoder and oracle can be compared bit for bit.
+ * Build with -ffp-contract=off (oracle/Makefile): every fused multiply-add below is an explicit fmaf. */
+static int f2i_(float x) { int i; memcpy(&i, &x, 4); return i; }
+static float i2f_(int i) { float x; memcpy(&x, &i, 4); return x; }
+
+static float exp_neg_(float d) { /* e^d, d <= 0; 0 below -86 */
+  if (!(d >= -86.0f)) return 0.0f;
+  const float n = rintf(d * 1.44269504088896341f);
+  float r = fmaf(n, -0.693359375f, d);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  const float y = fmaf(p, r2, r) + 1.0f;
+  return i2f_(f2i_(y) + ((int)n << 23));
+}
+
+static float log_pos_(float x) { /* ln x, x a positive normal float */
+  const int bits = f2i_(x);
+  int e = (bits >> 23) - 127;
+  float m = i2f_((bits & 0x007fffff) | 0x3f800000);
+  if (m > 1.41421356237309505f) {
+    m = m * 0.5f;
+    e += 1;
+  }
+  const float f = m - 1.0f;
+  const float z = f * f;
+  float y = 7.0376836292e-2f;
+  y = fmaf(y, f, -1.1514610310e-1f);
+  y = fmaf(y, f, 1.1676998740e-1f);
+  y = fmaf(y, f, -1.2420140846e-1f);
+  y = fmaf(y, f, 1.4249322787e-1f);
+  y = fmaf(y, f, -1.6668057665e-1f);
+  y = fmaf(y, f, 2.0000714765e-1f);
+  y = fmaf(y, f, -2.4999993993e-1f);
+  y = fmaf(y, f, 3.3333331174e-1f);
+  y = y * f;
+  y = y * z;
+  const float fe = (float)e;
+  y = fmaf(fe, -2.12194440e-4f, y);
+  y = fmaf(z, -0.5f, y);
+  float r = f + y;
+  r = fmaf(fe, 0.693359375f, r);
+  return r;
+}
+
+static float lse2(float a, float b) { /* ctc_loss_util.h LogSumExp */
   if (a == -INFINITY) return b;
   if (b == -INFINITY) return a;
-  return a > b ? a + log1pf(expf(b - a)) : b + log1pf(expf(a - b));
+  const float m = a > b ? a : b;
+  const float d = (a > b ? b : a) - m;
+  return m + log_pos_(1.0f + exp_neg_(d));
 }
+
+/* exported so the tests can check the pair against libm (accuracy) and pin its bits (known answers) */
+float chiron_oracle_ctc_exp(float d) { return exp_neg_(d); }
+float chiron_oracle_ctc_log(float x) { return log_pos_(x); }
+float chiron_oracle_ctc_lse(float a, float b) { return lse2(a, b); }
 
 static int bottom_of(const bnode* nd, const int* leaves, int nl) {
   int bi = 0;
@@ -320,8 +381,8 @@ int chiron_oracle_beam(const float* logits, const int* seq_len, int B, int T, in
       const float* lg = logits + ((size_t)b * T + t) * K;
       float mx = lg[0], s = 0.f, logp[5];
       for (int k = 1; k < K; ++k) mx = lg[k] > mx ? lg[k] : mx;
-      for (int k = 0; k < K; ++k) s += expf(lg[k] - mx);
-      const float lse = logf(s);
+      for (int k = 0; k < K; ++k) s += exp_neg_(lg[k] - mx);
+      const float lse = log_pos_(s);
       for (int k = 0; k < K; ++k) logp[k] = (lg[k] - mx) - lse;
       /* branches = leaves sorted by descending newp.total (insertion sort, stable) */
       int nbr = nl;
@@ -391,14 +452,18 @@ int chiron_oracle_beam(const float* logits, const int* seq_len, int B, int T, in
             cand = ch->n_total > nd[leaves[bot]].n_total;
           }
           if (cand) {
+            ch->in_leaves = 1;
             if (nl >= beam) {
+              /* TF's TopN pops its bottom and pushes the newcomer; which of several EQUAL totals is the bottom, and
+               * where the newcomer sits among equals, is left to the heap.  Convention here (and in the device
+               * kernels): the bottom is the first minimum in container order and the newcomer takes its place. */
               bnode* bt = &nd[leaves[bot]];
               bt->n_total = bt->n_blank = bt->n_label = -INFINITY;
               bt->in_leaves = 0;
-              leaves[bot] = leaves[--nl];
+              leaves[bot] = ci;
+            } else {
+              leaves[nl++] = ci;
             }
-            ch->in_leaves = 1;
-            leaves[nl++] = ci;
           } else {
             ch->o_total = ch->o_blank = ch->o_label = -INFINITY;
             ch->n_total = ch->n_blank = ch->n_label = -INFINITY;

@@ -20,7 +20,10 @@ import math
 
 import numpy as np
 
-BN_EPS = 1e-5          # cnn.py:125 (epsilon=1e-5), cnn.py:188
+# cnn.py:125 (epsilon=1e-5), cnn.py:188.  The graphs are float32, so the constant the reference's BN adds is
+# float32(1e-5) = 9.999999747378752e-06 (the value of .../batchnorm_1/add/y in the shipped .meta, tests/golden/meta_graph.json);
+# the float64 oracle uses that same number, not the double 1e-5.
+BN_EPS = float(np.float32(1e-5))
 FORGET_BIAS = 1.0      # tf LSTMCell default forget_bias, const 1.0 in .meta
 
 
@@ -54,7 +57,7 @@ def conv1d_same(x, w, stride=1):
 def bn_apply(x, scale, offset, mean, var):
     """tf.nn.batch_normalization association order (.meta batchnorm_1/*):
     inv = rsqrt(var+eps)*scale; y = x*inv + (offset - mean*inv)."""
-    inv = scale / np.sqrt(var + x.dtype.type(BN_EPS))
+    inv = (1.0 / np.sqrt(var + x.dtype.type(BN_EPS))) * scale
     return x * inv + (offset - mean * inv)
 
 

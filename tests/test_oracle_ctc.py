@@ -98,3 +98,78 @@ def test_c_beam_oracle_matches_python_and_exhaustive(built, seed):
         r2, l2 = co.beam_search_decode(lg, sl, w)
         assert r1 == r2
         np.testing.assert_allclose(l1, l2, rtol=0, atol=1e-4)
+
+
+def test_decoder_exp_log_pair_accuracy_and_known_bits():
+    """The beam-search oracle (and the device decoder, chiron_amd/csrc/ctc_math.h) fix e^x / ln x to a sequence of
+    exactly-specified float operations instead of libm.  Here: the pair is accurate to ~1 ulp against float64 (so it is
+    a faithful stand-in for the expf / logf / log1pf TF calls), and a handful of outputs are pinned by their bits, so
+    any change to the sequence is caught on the CPU before it shows up as a device / oracle mismatch."""
+    import struct
+    from oracle import c_oracle
+    rng = np.random.RandomState(0)
+    d = -np.abs(np.concatenate([rng.uniform(0, 86, 4000), rng.uniform(0, 1, 1000), [0.0, 1e-8, 86.0]])).astype(np.float32)
+    got = np.array([c_oracle.ctc_exp(v) for v in d], dtype=np.float64)
+    want = np.exp(d.astype(np.float64))
+    ulp = np.spacing(want.astype(np.float32)).astype(np.float64)
+    assert np.max(np.abs(got - want) / ulp) < 1.5
+    assert c_oracle.ctc_exp(-87.0) == 0.0 and c_oracle.ctc_exp(-np.inf) == 0.0 and c_oracle.ctc_exp(0.0) == 1.0
+    x = np.concatenate([rng.uniform(1, 2, 3000), rng.uniform(1, 8, 2000), [1.0, 2.0, 5.0]]).astype(np.float32)
+    got = np.array([c_oracle.ctc_log(v) for v in x], dtype=np.float64)
+    want = np.log(x.astype(np.float64))
+    assert np.max(np.abs(got - want)) < 2.5e-7           # ~1 ulp near ln 8, absolute near 1 where ln x -> 0
+    assert c_oracle.ctc_log(1.0) == 0.0
+    # log-sum-exp: symmetric, -inf is the identity, close to float64
+    for a, b in ((-1.0, -2.5), (-30.0, -30.0), (-0.1, -90.0), (-700.0, -701.5)):
+        v = c_oracle.ctc_lse(a, b)
+        assert v == c_oracle.ctc_lse(b, a)
+        assert abs(v - np.logaddexp(a, b)) < 4e-7 * max(1.0, abs(v))
+    assert c_oracle.ctc_lse(-np.inf, -3.0) == -3.0 and c_oracle.ctc_lse(-3.0, -np.inf) == -3.0
+    bits = lambda v: struct.unpack("<I", struct.pack("<f", v))[0]
+    kat = {"exp(-1)": bits(c_oracle.ctc_exp(-1.0)), "exp(-0.3)": bits(c_oracle.ctc_exp(-0.3)),
+           "exp(-20.5)": bits(c_oracle.ctc_exp(-20.5)), "log(1.5)": bits(c_oracle.ctc_log(1.5)),
+           "log(3.7)": bits(c_oracle.ctc_log(3.7)), "lse(-1,-2.5)": bits(c_oracle.ctc_lse(-1.0, -2.5))}
+    assert kat == CTC_MATH_KAT, kat
+
+
+CTC_MATH_KAT = {"exp(-1)": 1052531378, "exp(-0.3)": 1061004867, "exp(-20.5)": 816566744, "log(1.5)": 1053792543,
+                "log(3.7)": 1067939699, "lse(-1,-2.5)": 3209457709}
+
+
+def test_device_header_restates_the_same_operations(tmp_path):
+    """chiron_amd/csrc/ctc_math.h (what beam.hip compiles for the GPU) built for the host with g++ gives, input for
+    input, the bits of the oracle's own restatement: the two files describe one function."""
+    import ctypes
+    import os
+    import subprocess
+    from oracle import c_oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "shim.cpp"
+    src.write_text('#include "ctc_math.h"\n'
+                   'extern "C" float h_exp(float d) { return ctc_exp_neg(d); }\n'
+                   'extern "C" float h_log(float x) { return ctc_log_pos(x); }\n'
+                   'extern "C" float h_lse(float a, float b) { return ctc_log_sum_exp(a, b); }\n'
+                   'extern "C" void h_lsm(const float* x, float* o) { ctc_log_softmax<5>(x, o); }\n')
+    so = tmp_path / "shim.so"
+    subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-shared", "-fPIC", "-Wno-unknown-pragmas",
+                           "-I", os.path.join(root, "chiron_amd", "csrc"), str(src), "-o", str(so)])
+    lib = ctypes.CDLL(str(so))
+    for fn, n in (("h_exp", 1), ("h_log", 1), ("h_lse", 2)):
+        getattr(lib, fn).restype = ctypes.c_float
+        getattr(lib, fn).argtypes = [ctypes.c_float] * n
+    rng = np.random.RandomState(1)
+    f32 = lambda v: np.float32(v).view(np.uint32)
+    for d in -np.abs(rng.uniform(0, 90, 5000)).astype(np.float32):
+        assert f32(lib.h_exp(d)) == f32(c_oracle.ctc_exp(d))
+    for x in rng.uniform(1, 8, 5000).astype(np.float32):
+        assert f32(lib.h_log(x)) == f32(c_oracle.ctc_log(x))
+    for a, b in (-np.abs(rng.randn(5000, 2)) * 40).astype(np.float32):
+        assert f32(lib.h_lse(a, b)) == f32(c_oracle.ctc_lse(a, b))
+    # the frame log-softmax: header vs oracle through a one-frame beam-1 decode (its log_prob is logp[argmax])
+    lib.h_lsm.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    for _ in range(200):
+        x = (rng.randn(5) * 3).astype(np.float32)
+        o = np.zeros(5, np.float32)
+        lib.h_lsm(x.ctypes.data, o.ctypes.data)
+        _, lp = c_oracle.beam(x.reshape(1, 1, 5), [1], 1)
+        assert f32(lp[0, 0]) == f32(o.max())
