@@ -12,11 +12,19 @@ Parity status (see DESIGN.md "Oracle"):
     PINNED by golden vectors captured from the reference's own Python
     functions (tests/golden/make_golden.py) and by the reference's checked-in
     example outputs (segments -> consensus, exact for all 5 reads).
-  * NN stages (CNN / BiLSTM / FC) and the two TF CTC decoders: the arithmetic
-    lives in tensorflow==1.15.0 (setup.py:28-29), which is absent from
-    /root/reference and not installable here; the trained weights
-    (*.data-00000-of-00001) are stripped too.  These restatements follow the
-    op composition recorded in the shipped .meta graphs and the published TF
-    1.15 kernels.  PARITY UNPINNED against real TF outputs; cross-checked
-    against torch CPU (conv1d / LSTMCell) and brute-force CTC enumeration.
+  * NN stages (CNN / BiLSTM / FC): the arithmetic lives in tensorflow==1.15.0
+    (setup.py:28-29), absent from /root/reference and not installable here, and
+    the trained weights (*.data-00000-of-00001) are stripped, so there are no
+    TF-produced logits.  The COMPOSITION is pinned to the reference all the
+    same: tests/golden/make_meta_golden.py executes the node lists of the
+    shipped MetaGraphDefs (chiron/model/*/final.ckpt-*.meta) op by op in
+    float64 and tests/test_meta_golden.py holds nn_oracle to those activations
+    at 1e-12, plus a structural digest (strides, BN epsilon / association,
+    LSTM gate order, forget bias, masking, ReverseSequence, FC head, decoder
+    attrs).  Per-op arithmetic is restated and cross-checked against torch CPU.
+  * the two TF CTC decoder kernels (greedy, beam search): not in the graphs'
+    node lists as code, only as ops with attrs (pinned: beam_width,
+    merge_repeated=False, top_paths=1).  PARITY UNPINNED against TF's kernels;
+    validated by the reference's own mapping() goldens (greedy) and exhaustive
+    CTC enumeration (beam).
 """

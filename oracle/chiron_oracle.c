@@ -7,7 +7,10 @@
  * residual_layer, :334-371 getcnnfeature; chiron/rnn.py:20-97 / :99-174 (TF LSTMCell under
  * dynamic_rnn with sequence_length); rnn.py:72-96 FC head;
  * tf.nn.ctc_greedy_decoder(merge_repeated=True) (chiron_eval.py:485-487, appendix A.4).
- * PARITY UNPINNED against TensorFlow itself (TF 1.15 and the trained weights are unavailable).
+ * Pinning: this file is checked against oracle/nn_oracle.py (tests/test_oracle_nn.py), which in turn is held to the
+ * executed node lists of the reference's shipped .meta graphs (tests/test_meta_golden.py).  The TF CTC kernels
+ * themselves are PARITY UNPINNED (TF 1.15 is unavailable): greedy is pinned by the reference's mapping() goldens,
+ * beam search by exhaustive enumeration.
  *
  * Weight blob order = include/chiron_amd.h.  desc = {n_blocks, (in,out,k,stride,i_bn)*n_blocks,
  * rnn_kind, layers, hidden, classes, bn_mode}.
@@ -19,7 +22,7 @@
 #include <omp.h>
 #endif
 
-#define BN_EPS 1e-5f
+#define BN_EPS 1e-5f /* float32(1e-5), the constant of .../batchnorm_1/add/y in the shipped graphs */
 
 static void same_pad(int w, int k, int s, int* out, int* left) {
   *out = (w + s - 1) / s;

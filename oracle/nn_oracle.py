@@ -3,9 +3,19 @@ the reference network: chiron/cnn.py residual stack, chiron/rnn.py BiLSTM and
 FC head, exactly as composed in the shipped graphs
 (chiron/model/*/final.ckpt-*.meta) and TF 1.15 op semantics.
 
-PARITY UNPINNED for these stages: tensorflow==1.15.0 and the trained weights
-are not available.  Cross-checked against
-torch CPU in tests/test_oracle_nn.py.
+PINNING: tensorflow==1.15.0 and the trained weights are not available here
+(SURVEY.md section 0, facts 1-3), so no TF-produced logits exist to compare
+with.  What IS reference-held is the trained graph itself: the MetaGraphDefs
+under chiron/model/*/ record every op of the network and how they are wired.
+tests/golden/make_meta_golden.py executes those node lists (tf.cond as
+Switch/Merge, dynamic_rnn as while-loop frames with TensorArrays) in float64 on
+seeded inputs at the graphs' own shapes, and tests/test_meta_golden.py holds this
+file to those activations at 1e-12 (population BN for DNA and RNA, the
+batch-statistics branch for DNA) and to the structural digest
+tests/golden/meta_graph.json.  The composition is therefore pinned to the
+reference; the arithmetic inside each primitive op (SAME-padded Conv2D, Sigmoid,
+Tanh, MatMul accumulation order) remains TF-kernel behaviour that can only be
+restated -- cross-checked against torch CPU in tests/test_oracle_nn.py.
 
 Inputs are plain dicts so that this file depends on nothing in the product:
 

@@ -122,10 +122,10 @@ def test_bn_modes():
     x = rng.randn(3, 11, 4) * 3 + 1
     w = {"s_bn/scale": rng.rand(4) + 0.5, "s_bn/offset": rng.randn(4), "s_bn/pop_mean": rng.randn(4), "s_bn/pop_var": rng.rand(4) + 0.1}
     pop = no.bn_site(x, w, "s", "population")
-    np.testing.assert_allclose(pop, (x - w["s_bn/pop_mean"]) / np.sqrt(w["s_bn/pop_var"] + 1e-5) * w["s_bn/scale"] + w["s_bn/offset"], rtol=1e-12)
+    np.testing.assert_allclose(pop, (x - w["s_bn/pop_mean"]) / np.sqrt(w["s_bn/pop_var"] + no.BN_EPS) * w["s_bn/scale"] + w["s_bn/offset"], rtol=1e-12)
     bat = no.bn_site(x, w, "s", "batch")     # HEAD simple_global_bn: moments over [0,1,2], biased var
     m, v = x.reshape(-1, 4).mean(0), x.reshape(-1, 4).var(0)
-    np.testing.assert_allclose(bat, (x - m) / np.sqrt(v + 1e-5) * w["s_bn/scale"] + w["s_bn/offset"], rtol=1e-12)
+    np.testing.assert_allclose(bat, (x - m) / np.sqrt(v + no.BN_EPS) * w["s_bn/scale"] + w["s_bn/offset"], rtol=1e-12)
 
 
 @pytest.mark.parametrize("kind", ["dna", "rna"])
