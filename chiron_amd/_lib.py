@@ -14,13 +14,13 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libchiron_amd.so")
 MAX_BLOCKS = 8
 CLASSES = 5
 
-ABI_VERSION = 2      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
+ABI_VERSION = 3      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
 F32, F16, F32_SPLIT = 0, 1, 2
 X_ON_DEVICE, WANT_PROB, WANT_LOGITS, NO_DECODE_COPY = 1, 2, 4, 8
-KERNAL_GLUE, KERNAL_STICK = 1, 2
+KERNAL_GLUE, KERNAL_STICK, KERNAL_SIMPLE = 1, 2, 3
 
 
 class ResBlock(C.Structure):
@@ -69,8 +69,10 @@ SYMBOLS = [
     ("chiron_engine_profile", C.c_int, [C.c_void_p, C.c_int32]),
     ("chiron_engine_profile_read", C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
     ("chiron_parse_signal_text", C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
-    ("chiron_assemble", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
-                                  C.c_int64, C.POINTER(C.c_int64)]),
+    ("chiron_assemble", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                  C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    ("chiron_overlap_displacement", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
+                                              C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("chiron_last_error", C.c_char_p, []),
     ("chiron_abi_version", C.c_int32, []),
 ]

@@ -1,13 +1,16 @@
-// Overlap-consensus vote (host C++): chiron/utils/easy_assembler.py glue_kernal :276-294,
-// stick_kernal :296-300, simple_assembly(_qs) :302-335 / :393-432, add_count(_qs) :381-387 / :435-442.
-// Reproduces the reference's quirks deliberately: the consensus length only accounts for segments
-// 1..n-1 (the `continue` for segment 0 skips the length update), so a single-segment read yields an
-// empty consensus; ties in the glue score keep the first (smallest) overlap.
+// Overlap-consensus vote (host C++): chiron/utils/easy_assembler.py glue_kernal :276-294, stick_kernal :296-300,
+// simple_assembly_kernal :212-250 (difflib matching blocks + Poisson-like offset prior), simple_assembly(_qs)
+// :302-335 / :393-432, add_count(_qs) :381-387 / :435-442.
+// Reproduces the reference's quirks deliberately: the consensus length only accounts for segments 1..n-1 (the
+// `continue` for segment 0 skips the length update), so a single-segment read yields an empty consensus; ties in the
+// glue score keep the first (smallest) overlap; a negative start clips the segment's head.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/chiron_amd.h"
 
@@ -15,7 +18,9 @@ namespace chiron {
 chiron_status set_error(chiron_status st, const char* fmt, ...);
 }
 
-static int64_t glue_disp(const uint8_t* cur, int64_t n, const uint8_t* prev, int64_t prev_n) {
+namespace {
+
+int64_t glue_disp(const uint8_t* cur, int64_t n, const uint8_t* prev, int64_t prev_n) {
   // max_overlap = min(math.floor(0.1 * prev_n), n)   -- same IEEE double product as the reference
   int64_t max_overlap = (int64_t)std::floor(0.1 * (double)prev_n);
   if (n < max_overlap) max_overlap = n;
@@ -33,23 +38,170 @@ static int64_t glue_disp(const uint8_t* cur, int64_t n, const uint8_t* prev, int
   return prev_n - best_i;
 }
 
-extern "C" chiron_status chiron_assemble(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg,
-                                         const double* seg_qs, int32_t kernal, double* counts, double* qs_sum,
-                                         int64_t cap, int64_t* out_len) {
-  if (!seg_off || !out_len || n_seg < 0) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_assemble: bad arguments");
-  if (kernal != CHIRON_KERNAL_GLUE && kernal != CHIRON_KERNAL_STICK)
-    return chiron::set_error(CHIRON_ERR_INVALID, "chiron_assemble: kernal %d (1=glue, 2=stick)", kernal);
-  // pass 1: displacements -> length
-  int64_t pos = 0, length = 0, extent = 0;
-  for (int64_t s = 0; s < n_seg; ++s) {
-    const int64_t n = seg_off[s + 1] - seg_off[s];
-    if (s > 0) {
-      const int64_t pn = seg_off[s] - seg_off[s - 1];
-      const int64_t disp = kernal == CHIRON_KERNAL_GLUE ? glue_disp(bases + seg_off[s], n, bases + seg_off[s - 1], pn) : pn;
-      pos += disp;
-      if (pos + n > length) length = pos + n;
+// ---- difflib.SequenceMatcher(None, a, b).get_matching_blocks() for byte sequences (Ratcliff-Obershelp as CPython
+// implements it: longest match in the whole rectangle first, then the pieces left and right of it).  Details that
+// change results and are therefore kept: `b2j` lists the positions of every element of b EXCEPT "popular" ones when
+// len(b) >= 200 (autojunk: an element occurring more than len(b)//100 + 1 times is dropped from the index, though it
+// still extends a match); the longest-match scan keeps the FIRST best (lowest i, then lowest j); the matched block is
+// then extended left and right over equal elements.
+struct Block {
+  int64_t i, j, k;
+};
+
+class Matcher {
+ public:
+  Matcher(const uint8_t* a, int64_t la, const uint8_t* b, int64_t lb) : a_(a), b_(b), la_(la), lb_(lb) {
+    for (int64_t j = 0; j < lb; ++j) b2j_[b[j]].push_back(j);
+    if (lb >= 200) {
+      const int64_t ntest = lb / 100 + 1;
+      for (auto& idx : b2j_)
+        if ((int64_t)idx.size() > ntest) idx.clear();
     }
-    if (pos + n > extent) extent = pos + n;
+    len_cur_.assign(lb + 1, 0);
+    len_new_.assign(lb + 1, 0);
+  }
+
+  Block longest(int64_t alo, int64_t ahi, int64_t blo, int64_t bhi) {
+    int64_t besti = alo, bestj = blo, bestsize = 0;
+    // j2len[j] = length of the longest match ending with a[i-1], b[j]; stored at index j + 1 so that j - 1 = -1 is slot 0
+    touched_cur_.clear();
+    for (int64_t i = alo; i < ahi; ++i) {
+      touched_new_.clear();
+      for (int64_t j : b2j_[a_[i]]) {
+        if (j < blo) continue;
+        if (j >= bhi) break;
+        const int64_t k = len_cur_[j] + 1;   // len_cur_[j] is j2len[j - 1]
+        len_new_[j + 1] = k;
+        touched_new_.push_back(j + 1);
+        if (k > bestsize) {
+          besti = i - k + 1;
+          bestj = j - k + 1;
+          bestsize = k;
+        }
+      }
+      for (int64_t t : touched_cur_) len_cur_[t] = 0;
+      len_cur_.swap(len_new_);
+      touched_cur_.swap(touched_new_);
+    }
+    for (int64_t t : touched_cur_) len_cur_[t] = 0;
+    while (besti > alo && bestj > blo && a_[besti - 1] == b_[bestj - 1]) {
+      --besti;
+      --bestj;
+      ++bestsize;
+    }
+    while (besti + bestsize < ahi && bestj + bestsize < bhi && a_[besti + bestsize] == b_[bestj + bestsize]) ++bestsize;
+    return Block{besti, bestj, bestsize};
+  }
+
+  // sorted by (i, j); the terminating (la, lb, 0) entry of difflib is appended by the caller
+  std::vector<Block> blocks() {
+    struct Rect {
+      int64_t alo, ahi, blo, bhi;
+    };
+    std::vector<Rect> todo{{0, la_, 0, lb_}};
+    std::vector<Block> out;
+    while (!todo.empty()) {
+      const Rect r = todo.back();
+      todo.pop_back();
+      const Block m = longest(r.alo, r.ahi, r.blo, r.bhi);
+      if (m.k == 0) continue;
+      out.push_back(m);
+      if (r.alo < m.i && r.blo < m.j) todo.push_back({r.alo, m.i, r.blo, m.j});
+      if (m.i + m.k < r.ahi && m.j + m.k < r.bhi) todo.push_back({m.i + m.k, r.ahi, m.j + m.k, r.bhi});
+    }
+    std::sort(out.begin(), out.end(), [](const Block& x, const Block& y) { return x.i != y.i ? x.i < y.i : (x.j != y.j ? x.j < y.j : x.k < y.k); });
+    return out;
+  }
+
+ private:
+  const uint8_t *a_, *b_;
+  int64_t la_, lb_;
+  std::vector<int64_t> b2j_[256];
+  std::vector<int64_t> len_cur_, len_new_, touched_cur_, touched_new_;
+};
+
+// easy_assembler.py:212-250.  For every diagonal offset (position in prev minus position in cur) that carries a
+// matching block -- plus the offset lb - la of difflib's terminating empty block -- the score is
+//   |off| * ln(rate) - ln(|off|!) + matched * ln(p_same / 0.25) + 0 * ln(p_diff / 0.25),
+// rate = N * jump_step_ratio for off >= 0 and back_ratio * N * jump_step_ratio for off < 0 (N = len(cur)); the
+// displacement is the first offset (in order of first appearance among the sorted blocks) with the largest score.
+// Constants exactly as the reference writes them.
+int64_t simple_disp(const uint8_t* cur, int64_t n, const uint8_t* prev, int64_t prev_n, double error_rate, double jump_step_ratio,
+                    double* best_log_px) {
+  const double back_ratio = 6.5 * 10e-4;
+  const double p_same = 1 - 2 * error_rate + 26.0 / 25 * std::pow(error_rate, 2.0);
+  const double p_diff = 1 - p_same;
+  const double l_same = std::log(p_same / 0.25), l_diff = std::log(p_diff / 0.25);
+  Matcher m(cur, n, prev, prev_n);
+  std::vector<Block> bl = m.blocks();
+  bl.push_back(Block{n, prev_n, 0});
+  std::vector<int64_t> offs;      // insertion order of the reference's dicts
+  std::vector<int64_t> matched;
+  for (const Block& b : bl) {
+    const int64_t off = b.j - b.i;
+    size_t q = 0;
+    while (q < offs.size() && offs[q] != off) ++q;
+    if (q == offs.size()) {
+      offs.push_back(off);
+      matched.push_back(0);
+    }
+    matched[q] += b.k;
+  }
+  const double l_fwd = std::log((double)n * jump_step_ratio);
+  const double l_back = std::log(back_ratio * (double)n * jump_step_ratio);
+  int64_t best = 0;
+  double best_v = 0;
+  for (size_t q = 0; q < offs.size(); ++q) {
+    const int64_t off = offs[q];
+    const int64_t k = off < 0 ? -off : off;
+    double lfact = 0;   // sum(log(x + 1) for x in range(k)), summed in that order
+    for (int64_t x = 0; x < k; ++x) lfact += std::log((double)(x + 1));
+    double v = (double)k * (off < 0 ? l_back : l_fwd) - lfact;
+    v += (double)matched[q] * l_same;
+    v += 0.0 * l_diff;
+    if (q == 0 || v > best_v) {
+      best_v = v;
+      best = off;
+    }
+  }
+  if (best_log_px) *best_log_px = best_v;
+  return best;
+}
+
+int64_t displacement(int32_t kernal, const uint8_t* cur, int64_t n, const uint8_t* prev, int64_t pn, double error_rate,
+                     double jump_step_ratio, double* log_px) {
+  if (log_px) *log_px = 0;
+  if (kernal == CHIRON_KERNAL_GLUE) return glue_disp(cur, n, prev, pn);
+  if (kernal == CHIRON_KERNAL_STICK) return pn;
+  return simple_disp(cur, n, prev, pn, error_rate, jump_step_ratio, log_px);
+}
+
+bool known_kernal(int32_t k) { return k == CHIRON_KERNAL_GLUE || k == CHIRON_KERNAL_STICK || k == CHIRON_KERNAL_SIMPLE; }
+
+}  // namespace
+
+extern "C" chiron_status chiron_overlap_displacement(const uint8_t* cur, int64_t n, const uint8_t* prev, int64_t prev_n, int32_t kernal,
+                                                     double error_rate, double jump_step_ratio, int64_t* disp, double* log_px) {
+  if (!disp || n < 0 || prev_n < 0 || (n > 0 && !cur) || (prev_n > 0 && !prev))
+    return chiron::set_error(CHIRON_ERR_INVALID, "chiron_overlap_displacement: bad arguments");
+  if (!known_kernal(kernal)) return chiron::set_error(CHIRON_ERR_INVALID, "assembly kernal %d (1 = glue, 2 = stick, 3 = simple)", kernal);
+  *disp = displacement(kernal, cur, n, prev, prev_n, error_rate, jump_step_ratio, log_px);
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_assemble(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs, int32_t kernal,
+                                         double error_rate, double jump_step_ratio, double* counts, double* qs_sum, int64_t cap,
+                                         int64_t* out_len) {
+  if (!seg_off || !out_len || n_seg < 0) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_assemble: bad arguments");
+  if (!known_kernal(kernal)) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_assemble: kernal %d (1 = glue, 2 = stick, 3 = simple)", kernal);
+  // pass 1: where every segment starts (running position; may be negative with the simple kernel) and the length
+  std::vector<int64_t> start((size_t)n_seg, 0);
+  int64_t pos = 0, length = 0;
+  for (int64_t s = 1; s < n_seg; ++s) {
+    const int64_t n = seg_off[s + 1] - seg_off[s], pn = seg_off[s] - seg_off[s - 1];
+    pos += displacement(kernal, bases + seg_off[s], n, bases + seg_off[s - 1], pn, error_rate, jump_step_ratio, nullptr);
+    start[(size_t)s] = pos;
+    length = std::max(length, pos + n);
   }
   *out_len = length;
   if (length > cap) return chiron::set_error(CHIRON_ERR_OVERFLOW, "chiron_assemble: consensus needs %lld columns, capacity %lld", (long long)length, (long long)cap);
@@ -59,18 +211,15 @@ extern "C" chiron_status chiron_assemble(const uint8_t* bases, const int64_t* se
     memset(counts + r * cap, 0, sizeof(double) * length);
     if (qs_sum) memset(qs_sum + r * cap, 0, sizeof(double) * length);
   }
-  // pass 2: votes (columns beyond `length` are dropped exactly like concensus[:, :length])
-  pos = 0;
+  // pass 2: votes.  A segment starting left of column 0 loses its head (add_count); columns beyond `length` are
+  // dropped exactly like concensus[:, :length] (only segment 0 can reach past it)
   for (int64_t s = 0; s < n_seg; ++s) {
     const int64_t n = seg_off[s + 1] - seg_off[s];
-    if (s > 0) {
-      const int64_t pn = seg_off[s] - seg_off[s - 1];
-      pos += kernal == CHIRON_KERNAL_GLUE ? glue_disp(bases + seg_off[s], n, bases + seg_off[s - 1], pn) : pn;
-    }
     const uint8_t* seg = bases + seg_off[s];
     const double q = (seg_qs && qs_sum) ? seg_qs[s] : 0.0;
-    for (int64_t j = 0; j < n; ++j) {
-      const int64_t colx = pos + j;
+    const int64_t st = start[(size_t)s];
+    for (int64_t j = st < 0 ? -st : 0; j < n; ++j) {
+      const int64_t colx = st + j;
       if (colx >= length) break;
       const int b = seg[j] & 3;
       counts[b * cap + colx] += 1.0;
@@ -117,8 +266,10 @@ extern "C" chiron_status chiron_parse_signal_text(const char* text, size_t len, 
       memcpy(buf, tok, tl);
       buf[tl] = 0;
       char* stop = nullptr;
+      // strtod also reads C99 hexadecimal floats ("0x1p3"), which Python's float() / np.float32() refuse
+      const bool hex = memchr(buf, 'x', tl) || memchr(buf, 'X', tl);
       d = strtod(buf, &stop);
-      if (stop != buf + tl || tl == 0) return chiron::set_error(CHIRON_ERR_INVALID, "could not convert string to float: '%s'", buf);
+      if (hex || stop != buf + tl || tl == 0) return chiron::set_error(CHIRON_ERR_INVALID, "could not convert string to float: '%s'", buf);
       p = q;
     }
     if (n >= cap) return chiron::set_error(CHIRON_ERR_OVERFLOW, "chiron_parse_signal_text: more than %zu values", cap);

@@ -27,33 +27,43 @@ from .unix_time import unix_time
 BASES = "ACGT"
 
 
+def _rows_of(sparse):
+    """Row boundaries of a row-major sorted SparseTensor -> (row ids that occur, start offset of each, end offsets)."""
+    rows = sparse.indices[:, 0]
+    if rows.shape[0] == 0:
+        empty = np.zeros(0, dtype=np.int64)
+        return empty, empty, empty
+    starts = np.concatenate(([0], np.flatnonzero(rows[1:] != rows[:-1]) + 1))
+    return rows[starts], starts, np.concatenate((starts[1:], [rows.shape[0]]))
+
+
 def sparse2dense(predict_val):
-    """chiron_eval.py:36-66: (decoded SparseTensors, log_prob) -> ragged reads + the row ids that
-    have a non-empty decode (rows with an empty decode vanish)."""
+    """chiron_eval.py:36-66: (decoded SparseTensors, log_prob) -> per decoder output the ragged list of reads (one
+    array of base indices per row that decoded to something) and the ids of those rows.  Rows with an empty decode do
+    not appear in a SparseTensor, hence not here either."""
     predict_read, uniq_list = [], []
     for decode in predict_val[0]:
-        unique, pre_counts = np.unique(decode.indices[:, 0], return_counts=True)
-        uniq_list.append(unique)
-        pos = 0
-        reads = []
-        for c in pre_counts:
-            reads.append(decode.values[pos:pos + c])
-            pos += c
-        predict_read.append(reads)
+        ids, starts, ends = _rows_of(decode)
+        predict_read.append([decode.values[a:b] for a, b in zip(starts, ends)])
+        uniq_list.append(ids)
     return predict_read, uniq_list
 
 
 def slice_sparse_tensor(input_sp, start, end):
-    """chiron_eval.py:68-83."""
-    mask = np.logical_and(input_sp.indices[:, 0] >= start, input_sp.indices[:, 0] < end)
-    new_indices = input_sp.indices[mask] - [start, 0]
-    return SparseTensor(indices=new_indices, values=input_sp.values[mask],
+    """chiron_eval.py:68-83: the rows [start, end) of a SparseTensor, renumbered from 0 (same dense width).  The
+    decoders emit indices sorted by row, so the slice is one contiguous range found by bisection."""
+    rows = input_sp.indices[:, 0]
+    lo, hi = np.searchsorted(rows, [start, end], side="left")
+    indices = input_sp.indices[lo:hi].copy()
+    indices[:, 0] -= start
+    return SparseTensor(indices=indices, values=input_sp.values[lo:hi],
                         dense_shape=np.asarray([end - start, input_sp.dense_shape[1]]))
 
 
 def slice_ctc_decoding_result(input_decode, start, end):
-    """chiron_eval.py:85-98."""
-    return ([slice_sparse_tensor(d, start, end) for d in input_decode[0]], input_decode[1][start:end, :])
+    """chiron_eval.py:85-98: slice every decoder output and the [batch, 1] log-probabilities alike."""
+    decoded, log_prob = input_decode
+    return [slice_sparse_tensor(d, start, end) for d in decoded], log_prob[start:end, :]
 
 
 def index2base(read):
@@ -72,59 +82,85 @@ def get_assembler_kernal(jump, segment_len):
 
 
 def qs(consensus, consensus_qs, output_standard="phred+33"):
-    """chiron_eval.py:152-174."""
-    sort_ind = np.argsort(consensus, axis=0)
-    L = consensus.shape[1]
-    cols = np.arange(L)[np.newaxis, :]
-    sorted_consensus = consensus[sort_ind, cols]
-    sorted_consensus_qs = consensus_qs[sort_ind, cols]
-    quality_score = 10 * (np.log10((sorted_consensus[3, :] + 1) / (sorted_consensus[2, :] + 1))) + \
-        sorted_consensus_qs[3, :] / sorted_consensus[3, :] / np.log(10)
+    """chiron_eval.py:152-174: per consensus column, with n1 >= n2 the two largest vote counts and Q the summed segment
+    quality behind the winning base:   q = 10 log10((n1 + 1) / (n2 + 1)) + (Q / n1) / ln 10,   truncated to int.
+    Among equal top counts the reference's ascending argsort leaves the highest base index last, i.e. that base's Q is
+    used; kept.  A column nobody voted for (n1 = 0; the reference would divide 0 by 0 and fail in chr()) gets q = 0."""
+    counts = np.asarray(consensus, dtype=np.float64)
+    n_col = counts.shape[1]
+    if n_col == 0:
+        return np.zeros(0, dtype=int) if output_standard == "number" else ""
+    top = counts.shape[0] - 1 - np.argmax(counts[::-1], axis=0)      # last index among the maxima
+    n1 = counts[top, np.arange(n_col)]
+    n2 = np.partition(counts, -2, axis=0)[-2]
+    q_top = np.asarray(consensus_qs, dtype=np.float64)[top, np.arange(n_col)]
+    voted = n1 > 0
+    score = np.zeros(n_col)
+    score[voted] = 10 * np.log10((n1[voted] + 1) / (n2[voted] + 1)) + q_top[voted] / n1[voted] / np.log(10)
+    score = score.astype(int)
     if output_standard == "number":
-        return quality_score.astype(int)
-    elif output_standard == "phred+33":
-        return "".join(chr(x + 33) for x in quality_score.astype(int))
+        return score
+    if output_standard == "phred+33":
+        return "".join(map(chr, score + 33))
+    raise ValueError("output_standard must be 'number' or 'phred+33'")
+
+
+class OutputTree(object):
+    """The folders `chiron call` fills (README.md:154-160): result/ (one consensus per read), segments/ (one record per
+    window), meta/ (timings).  One writer per file type; chiron_eval.py:176-242 holds the formats."""
+
+    def __init__(self, root, suffix="fasta", concise=False, rna=False):
+        self.root, self.suffix, self.concise, self.rna = root, suffix, concise, rna
+
+    def _path(self, folder, file_pre, ext):
+        path = os.path.join(self.root, folder, file_pre + "." + ext)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        return path
+
+    def consensus(self, file_pre, sequence, quality=None):
+        """result/<pre>.fastq = @name / sequence / + / quality (each line terminated); result/<pre>.fasta = >name /
+        sequence WITHOUT a final newline (chiron_eval.py:216-221)."""
+        if self.rna:                                          # chiron_eval.py:204-205
+            sequence = sequence.replace("T", "U").replace("t", "u")
+        with open(self._path("result", file_pre, self.suffix), "w") as f:
+            if self.suffix == "fastq" and quality is not None:
+                f.write("@%s\n%s\n+\n%s\n" % (file_pre, sequence, quality))
+            else:
+                f.write(">%s\n%s" % (file_pre, sequence))
+        return sequence
+
+    def segments(self, file_pre, reads, qualities=None):
+        """segments/<pre>.<suffix>: a FASTA-style record per window, named <pre><window index>; with per-window quality
+        strings (never passed by `chiron call`, chiron_eval.py:460-462) a FASTQ record follows each."""
+        with open(self._path("segments", file_pre, self.suffix), "w") as f:
+            for k, read in enumerate(reads):
+                f.write(">%s%d\n%s\n" % (file_pre, k, read))
+                if self.suffix == "fastq" and qualities is not None:
+                    f.write("@%s%d\n%s\n+\n%s\n" % (file_pre, k, read, qualities[k]))
+
+    def meta(self, file_pre, n_bases, stamps, settings):
+        """meta/<pre>.meta: stage durations derived from the cumulative stamps (start, reading, basecall, assembly) and
+        the run's settings, three header/value line pairs (chiron_eval.py:229-242)."""
+        start, reading, basecall_end, assembly_end = stamps
+        total = time.time() - start
+        spans = (reading, basecall_end - reading, assembly_end - basecall_end, total - assembly_end, total)
+        with open(self._path("meta", file_pre, "meta"), "w") as f:
+            f.write("# Reading Basecalling assembly output total rate(bp/s)\n")
+            f.write(" ".join("%5.3f" % v for v in spans + (n_bases / total,)) + "\n")
+            f.write("# read_len batch_size segment_len jump start_pos\n")
+            f.write("%d %d %d %d %d\n" % (n_bases, settings.batch_size, settings.segment_len, settings.jump, settings.start))
+            f.write("# input_name model_name\n")
+            f.write("%s %s\n" % (settings.input, settings.model))
 
 
 def write_output(segments, consensus, time_list, file_pre, global_setting, concise=False, suffix="fasta",
                  seg_q_score=None, q_score=None):
-    """chiron_eval.py:176-242: result/<pre>.<suffix>, segments/<pre>.<suffix>, meta/<pre>.meta."""
-    start_time, reading_time, basecall_time, assembly_time = time_list
-    result_folder = os.path.join(global_setting.output, "result")
-    seg_folder = os.path.join(global_setting.output, "segments")
-    meta_folder = os.path.join(global_setting.output, "meta")
-    for d in (result_folder,) + (() if concise else (seg_folder, meta_folder)):
-        os.makedirs(os.path.dirname(os.path.join(d, file_pre)), exist_ok=True)
-    path_con = os.path.join(result_folder, file_pre + "." + suffix)
-    if global_setting.mode == "rna":
-        consensus = consensus.replace("T", "U").replace("t", "u")
-    with open(path_con, "w+") as out_con:
-        if not concise:
-            with open(os.path.join(seg_folder, file_pre + "." + suffix), "w+") as out_f:
-                for indx, read in enumerate(segments):
-                    out_f.write(">{}{}\n{}\n".format(file_pre, str(indx), read))
-                    if (suffix == "fastq") and (seg_q_score is not None):
-                        out_f.write("@{}{}\n{}\n+\n{}\n".format(file_pre, str(indx), read, seg_q_score[indx]))
-        if (suffix == "fastq") and (q_score is not None):
-            out_con.write("@{}\n{}\n+\n{}\n".format(file_pre, consensus, q_score))
-        else:
-            out_con.write(">{}\n{}".format(file_pre, consensus))
+    """chiron_eval.py:176-242 (same signature): consensus always; segments and meta unless `concise`."""
+    out = OutputTree(global_setting.output, suffix, concise, rna=getattr(global_setting, "mode", "dna") == "rna")
+    written = out.consensus(file_pre, consensus, q_score)
     if not concise:
-        with open(os.path.join(meta_folder, file_pre + ".meta"), "w+") as out_meta:
-            total_time = time.time() - start_time
-            output_time = total_time - assembly_time
-            assembly_time -= basecall_time
-            basecall_time -= reading_time
-            total_len = len(consensus)
-            total_time = time.time() - start_time
-            out_meta.write("# Reading Basecalling assembly output total rate(bp/s)\n")
-            out_meta.write("%5.3f %5.3f %5.3f %5.3f %5.3f %5.3f\n" % (
-                reading_time, basecall_time, assembly_time, output_time, total_time, total_len / total_time))
-            out_meta.write("# read_len batch_size segment_len jump start_pos\n")
-            out_meta.write("%d %d %d %d %d\n" % (total_len, global_setting.batch_size, global_setting.segment_len,
-                                                 global_setting.jump, global_setting.start))
-            out_meta.write("# input_name model_name\n")
-            out_meta.write("%s %s\n" % (global_setting.input, global_setting.model))
+        out.segments(file_pre, segments, seg_q_score)
+        out.meta(file_pre, len(written), time_list, global_setting)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -7,12 +7,18 @@ with a throttle (_Result_Collection :59-109), per-file collection in batch order
 `simple` overlap consensus with quality scores and the chiron_eval writers (do_inference :191-255).
 
 The reference speaks gRPC to TensorFlow Serving; neither TF Serving's protos nor a network exist here, so the wire
-is `multiprocessing.connection` (length-prefixed pickles of numpy arrays, HMAC-authenticated) on 127.0.0.1 -- the
-request/response field names and semantics are the signature's.  As in export_test.py:34 the server divides
+is a length-prefixed binary frame over `multiprocessing.connection` on 127.0.0.1: a JSON header (method, scalar
+fields, and name / dtype / shape of every tensor) followed by the tensors' raw little-endian bytes.  Nothing is
+unpickled on either side (only send_bytes / recv_bytes are used), dtypes are restricted to the signature's, and the
+connection handshake is HMAC-authenticated with a per-deployment key: the server generates one (or takes
+CHIRON_SERVE_AUTHKEY / --authkey-file) -- there is no built-in default.  The request/response field names and
+semantics are the signature's.  As in export_test.py:34 the server divides
 seq_len by the model's ratio and rounds (round-half-even, tf.round) before decoding, and decodes with its own
 beam width (export_test.py:36-39: ctc_beam_search_decoder, merge_repeated=False); beam_width 0 selects greedy.
 """
+import json
 import os
+import struct
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -27,17 +33,79 @@ from .engine import seq_len_for_engine
 
 SIGNATURE_INPUTS = ("x", "seq_len")
 SIGNATURE_OUTPUTS = ("indices", "values", "dense_shape", "logits", "prob_logits", "log_prob")
-DEFAULT_AUTHKEY = b"chiron-predict"
+WIRE_DTYPES = {"float32": np.dtype("<f4"), "int32": np.dtype("<i4"), "int64": np.dtype("<i8")}
+MAX_FRAME = 1 << 31
+
+
+def make_authkey():
+    """A fresh per-deployment key for the connection handshake (hex so that it survives files and env vars)."""
+    return os.urandom(24).hex().encode("ascii")
+
+
+def authkey_from_env(path=None):
+    """Key from a 0600 file (`path`) or CHIRON_SERVE_AUTHKEY; None when neither is set."""
+    if path:
+        with open(path, "rb") as f:
+            return f.read().strip()
+    v = os.environ.get("CHIRON_SERVE_AUTHKEY")
+    return v.encode("ascii") if v else None
+
+
+def pack_frame(fields, tensors=None):
+    """-> bytes: u32 header length | JSON header | raw tensor bytes in header order"""
+    tensors = tensors or {}
+    arrays, blobs = [], []
+    for name, a in tensors.items():
+        if a is None:
+            continue
+        a = np.ascontiguousarray(a)
+        if a.dtype.name not in WIRE_DTYPES:
+            raise TypeError("tensor %r has dtype %s; the wire carries %s" % (name, a.dtype, sorted(WIRE_DTYPES)))
+        a = a.astype(WIRE_DTYPES[a.dtype.name], copy=False)
+        arrays.append({"name": name, "dtype": a.dtype.name, "shape": list(a.shape)})
+        blobs.append(a.tobytes())
+    header = json.dumps({"fields": fields, "tensors": arrays}).encode("utf-8")
+    return b"".join([struct.pack("<I", len(header)), header] + blobs)
+
+
+def unpack_frame(buf):
+    """-> (fields, {name: ndarray}); rejects anything that is not exactly header + declared tensors"""
+    buf = memoryview(buf)
+    if len(buf) < 4:
+        raise ValueError("short frame")
+    hlen, = struct.unpack_from("<I", buf, 0)
+    if 4 + hlen > len(buf):
+        raise ValueError("frame header overruns the frame")
+    head = json.loads(bytes(buf[4:4 + hlen]).decode("utf-8"))
+    pos = 4 + hlen
+    tensors = {}
+    for d in head.get("tensors", []):
+        dt = WIRE_DTYPES.get(d.get("dtype"))
+        shape = d.get("shape")
+        if dt is None or not isinstance(shape, list) or any((not isinstance(v, int)) or v < 0 for v in shape) or len(shape) > 4:
+            raise ValueError("bad tensor descriptor %r" % (d,))
+        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        if pos + n > len(buf):
+            raise ValueError("tensor %r overruns the frame" % d.get("name"))
+        tensors[str(d["name"])] = np.frombuffer(buf[pos:pos + n], dtype=dt).reshape(shape)
+        pos += n
+    if pos != len(buf):
+        raise ValueError("%d trailing bytes in frame" % (len(buf) - pos))
+    fields = head.get("fields", {})
+    if not isinstance(fields, dict):
+        raise ValueError("frame fields must be an object")
+    return fields, tensors
 
 
 class PredictServer(object):
     """One engine, many connections.  Every connection thread takes an engine slot for the duration of a request
     (engines have `n_slots` independent streams), so `n_slots` requests are in flight on the GPU at once."""
 
-    def __init__(self, engine, address=("127.0.0.1", 0), beam_width=0, authkey=DEFAULT_AUTHKEY):
+    def __init__(self, engine, address=("127.0.0.1", 0), beam_width=0, authkey=None):
         self.engine = engine
         self.beam_width = int(beam_width)
-        self._listener = Listener(address, authkey=authkey)
+        self.authkey = authkey if authkey else make_authkey()     # hand this to the clients of THIS server
+        self._listener = Listener(address, authkey=self.authkey)
         self.address = self._listener.address
         self._slots = list(range(engine.n_slots))
         self._slot_cv = threading.Condition()
@@ -113,24 +181,26 @@ class PredictServer(object):
         with conn:
             while True:
                 try:
-                    req = conn.recv()
+                    raw = conn.recv_bytes(MAX_FRAME)
                 except (EOFError, OSError):
                     return
                 try:
+                    req, tensors = unpack_frame(raw)
                     if req.get("method") == "signature":
-                        rep = {"inputs": SIGNATURE_INPUTS, "outputs": SIGNATURE_OUTPUTS, "segment_len": self.engine.segment_len,
-                               "T": self.engine.T, "ratio": self.engine.ratio, "max_batch": self.engine.max_batch,
-                               "beam_width": self.beam_width}
-                    else:
-                        missing = [k for k in SIGNATURE_INPUTS if k not in req.get("inputs", {})]
+                        rep = pack_frame({"inputs": list(SIGNATURE_INPUTS), "outputs": list(SIGNATURE_OUTPUTS),
+                                          "segment_len": self.engine.segment_len, "T": self.engine.T, "ratio": self.engine.ratio,
+                                          "max_batch": self.engine.max_batch, "beam_width": self.beam_width})
+                    elif req.get("method") == "predict":
+                        missing = [k for k in SIGNATURE_INPUTS if k not in tensors]
                         if missing:
                             raise KeyError("missing inputs %s" % missing)
-                        rep = {"outputs": self.predict(req["inputs"]["x"], req["inputs"]["seq_len"],
-                                                       want_logits=req.get("want_logits", True))}
+                        rep = pack_frame({}, self.predict(tensors["x"], tensors["seq_len"], want_logits=bool(req.get("want_logits", True))))
+                    else:
+                        raise ValueError("unknown method %r" % (req.get("method"),))
                 except Exception as exc:                             # the failure travels to the caller, like a gRPC status
-                    rep = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                    rep = pack_frame({"error": "%s: %s" % (type(exc).__name__, exc)})
                 try:
-                    conn.send(rep)
+                    conn.send_bytes(rep)
                 except (OSError, EOFError):
                     return
 
@@ -156,7 +226,9 @@ class PredictClient(object):
     """`stub.Predict` / `stub.Predict.future` of chiron_client.py:208-227 over the local wire.  Each in-flight
     request uses its own connection (a pool of `concurrency` of them)."""
 
-    def __init__(self, address, concurrency=4, authkey=DEFAULT_AUTHKEY):
+    def __init__(self, address, authkey, concurrency=4):
+        if not authkey:
+            raise ValueError("the server's authkey is required (PredictServer.authkey, --authkey-file or CHIRON_SERVE_AUTHKEY)")
         self.address = address
         self.authkey = authkey
         self._pool = ThreadPoolExecutor(max_workers=max(1, concurrency))
@@ -173,19 +245,23 @@ class PredictClient(object):
                 self._conns.append(c)
         return c
 
-    def _call(self, req):
+    def _call(self, fields, tensors=None):
         c = self._conn()
-        c.send(req)
-        rep = c.recv()
+        c.send_bytes(pack_frame(fields, tensors))
+        rep, out = unpack_frame(c.recv_bytes(MAX_FRAME))
         if "error" in rep:
             raise PredictError(rep["error"])
-        return rep
+        return rep, out
 
     def signature(self):
-        return self._call({"method": "signature"})
+        return self._call({"method": "signature"})[0]
 
     def predict(self, x, seq_len, want_logits=True):
-        return self._call({"method": "predict", "inputs": {"x": x, "seq_len": seq_len}, "want_logits": want_logits})["outputs"]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        seq_len = np.ascontiguousarray(np.asarray(seq_len).reshape(-1), dtype=np.int32)
+        out = self._call({"method": "predict", "want_logits": bool(want_logits)}, {"x": x, "seq_len": seq_len})[1]
+        out.setdefault("logits", None)
+        return out
 
     def predict_future(self, x, seq_len, want_logits=False):
         return self._pool.submit(self.predict, x, seq_len, want_logits)
@@ -210,16 +286,6 @@ class PredictClient(object):
 # -------------------------------------------------------------------------------------------------------------
 # the reference client's job: a folder of .signal files -> result/ segments/ meta/ through the server
 # -------------------------------------------------------------------------------------------------------------
-def sparse2dense(indices, values):
-    """chiron_client.py:111-131: rows of the SparseTensor in order, and the batch rows that decoded to something."""
-    unique, counts = np.unique(indices[:, 0], return_counts=True)
-    reads, pos = [], 0
-    for c in counts:
-        reads.append(values[pos:pos + c])
-        pos += c
-    return reads, unique
-
-
 def gen_file_list(input_path):
     """chiron_client.py:132-139 (os.walk for *.signal), sorted for determinism."""
     out = []
@@ -245,7 +311,7 @@ class ClientFlags(object):
     """FLAGS of chiron_client.py:257-283 (+ DNA_CONF / RNA_CONF :49-57)."""
 
     def __init__(self, input, output, server, mode="dna", batch_size=100, concurrency=4, extension="fastq", concise=False,
-                 segment_len=None, jump=None, start=0):
+                 segment_len=None, jump=None, start=0, authkey=None):
         if mode not in ("dna", "rna"):
             raise ValueError("Mode has to be either rna or dna.")
         self.input, self.output, self.server, self.mode = input, output, server, mode
@@ -253,6 +319,7 @@ class ClientFlags(object):
         self.segment_len = segment_len if segment_len else (400 if mode == "dna" else 2000)
         self.jump = jump if jump else (30 if mode == "dna" else 200)
         self.start = start
+        self.authkey = authkey
         self.recursive = True
         self.beam = 0
         self.model = "served"
@@ -263,7 +330,7 @@ def do_inference(FLAGS, client=None):
     own = client is None
     if own:
         host, port = FLAGS.server.rsplit(":", 1)
-        client = PredictClient((host, int(port)), concurrency=FLAGS.concurrency)
+        client = PredictClient((host, int(port)), FLAGS.authkey or authkey_from_env(), concurrency=FLAGS.concurrency)
     files = gen_file_list(FLAGS.input)
     pending = {}                                                     # file -> {batch index: (reads, probs)}
     expect = {}
@@ -275,7 +342,8 @@ def do_inference(FLAGS, client=None):
         def cb(fut):
             throttle.release()
             out = fut.result()
-            reads, uniq = sparse2dense(out["indices"], out["values"])
+            # chiron_client.py:111-131: the rows that decoded to something, in order
+            (reads,), (uniq,) = ce.sparse2dense(([ce.SparseTensor(out["indices"], out["values"], out["dense_shape"])], None))
             with lock:
                 pending.setdefault(f_p, {})[i] = (reads, out["prob_logits"][uniq])
                 expect[f_p] = n_batches
@@ -313,6 +381,24 @@ def do_inference(FLAGS, client=None):
     return results
 
 
+def start_server(a):
+    """engine + PredictServer for the parsed `server` arguments -> (server, engine)"""
+    from .engine import Engine
+    from .model import load_model
+    seg = a.segment_len if a.segment_len else (400 if a.mode == "dna" else 2000)
+    spec, weights, _ = load_model(a.model, allow_synthetic=a.synthetic_weights)
+    key = None
+    if a.authkey_file and os.path.exists(a.authkey_file):
+        key = authkey_from_env(a.authkey_file)
+    key = key or authkey_from_env() or make_authkey()
+    if a.authkey_file and not os.path.exists(a.authkey_file):
+        fd = os.open(a.authkey_file, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(key)
+    eng = Engine(spec, weights, max_batch=a.batch_size, segment_len=seg, n_slots=a.slots, max_beam=a.beam)
+    return PredictServer(eng, ("127.0.0.1", a.port), beam_width=a.beam, authkey=key), eng
+
+
 def main(argv=None):
     """python -m chiron_amd.serve server -m <model dir> [--port P] | client -i <signals> -o <out> --server host:port"""
     import argparse
@@ -327,7 +413,9 @@ def main(argv=None):
     sp.add_argument("--beam", type=int, default=50)                 # export_test.py beam_width flag
     sp.add_argument("--slots", type=int, default=2)
     sp.add_argument("--synthetic-weights", action="store_true")
+    sp.add_argument("--authkey-file", default=None, help="file holding the handshake key; created (0600) with a fresh key when absent")
     cp = sub.add_parser("client")
+    cp.add_argument("--authkey-file", default=None, help="the key file the server wrote (or set CHIRON_SERVE_AUTHKEY)")
     cp.add_argument("-i", "--input", required=True)
     cp.add_argument("-o", "--output", required=True)
     cp.add_argument("--server", default="127.0.0.1:8500")
@@ -338,15 +426,11 @@ def main(argv=None):
     cp.add_argument("--concise", action="store_true")
     a = ap.parse_args(argv)
     if a.cmd == "client":
-        res = do_inference(ClientFlags(a.input, a.output, a.server, a.mode, a.batch_size, a.concurrency, a.extension, a.concise))
+        res = do_inference(ClientFlags(a.input, a.output, a.server, a.mode, a.batch_size, a.concurrency, a.extension, a.concise,
+                                       authkey=authkey_from_env(a.authkey_file)))
         print("%d reads written to %s" % (len(res), a.output))
         return 0
-    from .engine import Engine
-    from .model import load_model
-    seg = a.segment_len if a.segment_len else (400 if a.mode == "dna" else 2000)
-    spec, weights = load_model(a.model, allow_synthetic=a.synthetic_weights)
-    eng = Engine(spec, weights, max_batch=a.batch_size, segment_len=seg, n_slots=a.slots, max_beam=a.beam)
-    srv = PredictServer(eng, ("127.0.0.1", a.port), beam_width=a.beam)
+    srv, eng = start_server(a)
     print("serving %s on %s:%d (beam %d); Ctrl-C to stop" % (a.model, srv.address[0], srv.address[1], a.beam))
     try:
         while True:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CHIRON_ABI_VERSION 2
+#define CHIRON_ABI_VERSION 3
 #define CHIRON_MAX_BLOCKS 8
 #define CHIRON_CLASSES 5 /* A,C,G,T,blank (rnn.py:25 class_n=5) */
 
@@ -188,17 +188,28 @@ chiron_status chiron_engine_profile_read(chiron_engine* e, chiron_kernel_stat* s
                                          int32_t* n_stats);
 
 /* Overlap-consensus vote, chiron/utils/easy_assembler.py:
- *   glue_kernal :276-294, stick_kernal :296-300, simple_assembly(_qs) :302-335 / :393-432,
- *   add_count(_qs) :381-387 / :435-442, and the argmax of chiron_eval.py:457.
- * bases: concatenated segments as 0..3; seg_off [n_seg+1] prefix offsets;
- * seg_qs [n_seg] per-segment quality (may be NULL); kernel: 1 = glue, 2 = stick.
- * Outputs (caller-allocated, capacity cap columns): counts [4][cap] float64,
- * qs_sum [4][cap] float64 (if seg_qs), *out_len = consensus length.
- * Returns CHIRON_ERR_OVERFLOW if cap is too small (then *out_len = needed).    */
+ *   glue_kernal :276-294, stick_kernal :296-300, simple_assembly_kernal :212-250 (difflib.SequenceMatcher matching
+ *   blocks + offset prior; `error_rate`, `jump_step_ratio` as in simple_assembly(bpreads, jump_step_ratio, error_rate,
+ *   kernal) :302), simple_assembly(_qs) :302-335 / :393-432, add_count(_qs) :381-387 / :435-442, and the argmax of
+ *   chiron_eval.py:457.
+ * bases: concatenated segments as 0..3; seg_off [n_seg+1] prefix offsets; seg_qs [n_seg] per-segment quality (may be
+ * NULL); kernal: one of CHIRON_KERNAL_*; error_rate / jump_step_ratio are read by the simple kernel only.
+ * Outputs (caller-allocated, capacity cap columns): counts [4][cap] float64, qs_sum [4][cap] float64 (if seg_qs),
+ * *out_len = consensus length.  Returns CHIRON_ERR_OVERFLOW if cap is too small (then *out_len = needed).
+ * Pure host code: callable without a GPU and from several threads at once.                                      */
 #define CHIRON_KERNAL_GLUE 1
 #define CHIRON_KERNAL_STICK 2
+#define CHIRON_KERNAL_SIMPLE 3
 chiron_status chiron_assemble(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs,
-                              int32_t kernal, double* counts, double* qs_sum, int64_t cap, int64_t* out_len);
+                              int32_t kernal, double error_rate, double jump_step_ratio, double* counts, double* qs_sum,
+                              int64_t cap, int64_t* out_len);
+
+/* One displacement of the vote above: where `cur` starts relative to the start of `prev` (the return value of
+ * glue_kernal / stick_kernal / simple_assembly_kernal; for the simple kernel *log_px receives its second return
+ * value, the score of the chosen offset; 0 otherwise; log_px may be NULL).                                       */
+chiron_status chiron_overlap_displacement(const uint8_t* cur, int64_t n, const uint8_t* prev, int64_t prev_n,
+                                          int32_t kernal, double error_rate, double jump_step_ratio, int64_t* disp,
+                                          double* log_px);
 
 /* Host-side reader of the reference's raw-signal text format: chiron_input.py:527-539 read_signal() --
  * `f.read().split()` converted to float32 -- whitespace/newline separated numbers.  Each token is parsed as a

@@ -52,11 +52,12 @@ static int fuzz_assemble(int iters) {
       off.push_back((int64_t)bases.size());
       qs.push_back((rnd() % 2000) / 100.0);
     }
-    const int kernal = 1 + (rnd() & 1);
+    const int kernal = 1 + (rnd() % 3);   // glue, stick, simple
+    const double jr = (rnd() & 1) ? 0.075 : 0.975;
     const bool with_qs = rnd() & 1;
     int64_t need = -1;
     // (a) capacity 0: either the consensus is empty or the call reports what it needs
-    chiron_status st = chiron_assemble(bases.data(), off.data(), n_seg, with_qs ? qs.data() : nullptr, kernal, nullptr, nullptr, 0, &need);
+    chiron_status st = chiron_assemble(bases.data(), off.data(), n_seg, with_qs ? qs.data() : nullptr, kernal, 0.2, jr, nullptr, nullptr, 0, &need);
     REQUIRE(st == CHIRON_OK || st == CHIRON_ERR_OVERFLOW || st == CHIRON_ERR_INVALID);
     REQUIRE(need >= 0 && need <= (int64_t)bases.size() + 1);
     if (st == CHIRON_ERR_INVALID) REQUIRE(need == 0 || true);
@@ -64,7 +65,7 @@ static int fuzz_assemble(int iters) {
     const int64_t cap = need;
     std::vector<double> counts(4 * (size_t)cap + 1, -7.0), qsum(4 * (size_t)cap + 1, -7.0);
     int64_t len2 = -1;
-    st = chiron_assemble(bases.data(), off.data(), n_seg, with_qs ? qs.data() : nullptr, kernal, counts.data(), with_qs ? qsum.data() : nullptr, cap, &len2);
+    st = chiron_assemble(bases.data(), off.data(), n_seg, with_qs ? qs.data() : nullptr, kernal, 0.2, jr, counts.data(), with_qs ? qsum.data() : nullptr, cap, &len2);
     REQUIRE(st == CHIRON_OK);
     REQUIRE(len2 == need);
     REQUIRE(counts[4 * (size_t)cap] == -7.0 && qsum[4 * (size_t)cap] == -7.0);
@@ -78,15 +79,28 @@ static int fuzz_assemble(int iters) {
     // (c) one column short must be refused, not overrun
     if (cap > 0) {
       int64_t len3 = -1;
-      st = chiron_assemble(bases.data(), off.data(), n_seg, nullptr, kernal, counts.data(), nullptr, cap - 1, &len3);
+      st = chiron_assemble(bases.data(), off.data(), n_seg, nullptr, kernal, 0.2, jr, counts.data(), nullptr, cap - 1, &len3);
       REQUIRE(st == CHIRON_ERR_OVERFLOW && len3 == need);
     }
   }
   // argument errors
   int64_t n = 0;
-  REQUIRE(chiron_assemble(nullptr, nullptr, 1, nullptr, 1, nullptr, nullptr, 0, &n) == CHIRON_ERR_INVALID);
+  REQUIRE(chiron_assemble(nullptr, nullptr, 1, nullptr, 1, 0.2, 1.0, nullptr, nullptr, 0, &n) == CHIRON_ERR_INVALID);
   const int64_t off1[2] = {0, 0};
-  REQUIRE(chiron_assemble(nullptr, off1, 1, nullptr, 3, nullptr, nullptr, 0, &n) == CHIRON_ERR_INVALID);
+  REQUIRE(chiron_assemble(nullptr, off1, 1, nullptr, 4, 0.2, 1.0, nullptr, nullptr, 0, &n) == CHIRON_ERR_INVALID);
+  // the displacement entry point on its own, incl. empty segments and long (autojunk) ones
+  for (int it = 0; it < iters; ++it) {
+    const int la = (it % 7 == 0) ? 150 + rnd() % 200 : rnd() % 50, lb = (it % 5 == 0) ? 190 + rnd() % 150 : rnd() % 50;
+    std::vector<uint8_t> a(la + 1), b(lb + 1);
+    for (auto& v : a) v = rnd() & 3;
+    for (auto& v : b) v = (rnd() % 3 == 0) ? rnd() & 3 : a[rnd() % a.size()];
+    int64_t disp = 0;
+    double lp = 0;
+    REQUIRE(chiron_overlap_displacement(a.data(), la, b.data(), lb, 1 + rnd() % 3, 0.2, 0.075, &disp, (rnd() & 1) ? &lp : nullptr) == CHIRON_OK);
+    REQUIRE(disp >= -(int64_t)la && disp <= (int64_t)lb);
+  }
+  REQUIRE(chiron_overlap_displacement(nullptr, 3, nullptr, 0, 1, 0.2, 1.0, &n, nullptr) == CHIRON_ERR_INVALID);
+  REQUIRE(chiron_overlap_displacement(nullptr, 0, nullptr, 0, 9, 0.2, 1.0, &n, nullptr) == CHIRON_ERR_INVALID);
   return 0;
 }
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == bound, "binding and header disagree: %s" % (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.chiron_abi_version() == 2
+    assert lib.chiron_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_weights_size_and_validation(built):
@@ -81,10 +81,10 @@ def test_chiron_assemble_errors(built):
     bases = np.zeros(4, np.uint8)
     off = np.asarray([0, 2, 4], np.int64)
     n = C.c_int64()
-    st = lib.chiron_assemble(bases.ctypes.data, off.ctypes.data, 2, None, 7, None, None, 0, C.byref(n))
+    st = lib.chiron_assemble(bases.ctypes.data, off.ctypes.data, 2, None, 7, 0.2, 1.0, None, None, 0, C.byref(n))
     assert st == _lib.ERR_INVALID
     counts = np.zeros((4, 1))
-    st = lib.chiron_assemble(bases.ctypes.data, off.ctypes.data, 2, None, _lib.KERNAL_STICK, counts.ctypes.data, None, 1, C.byref(n))
+    st = lib.chiron_assemble(bases.ctypes.data, off.ctypes.data, 2, None, _lib.KERNAL_STICK, 0.2, 1.0, counts.ctypes.data, None, 1, C.byref(n))
     assert st == _lib.ERR_OVERFLOW and n.value == 4
 
 

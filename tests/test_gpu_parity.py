@@ -654,7 +654,7 @@ def test_predict_signature_served_from_the_engine(dna):
     with ca.Engine(spec, w, max_batch=16, segment_len=400, n_slots=2, max_beam=50) as eng:
         direct = [eng.infer(x[a:a + 16], ca.seq_len_for_engine(ln[a:a + 16], eng.ratio), beam_width=50, want_prob=True,
                             want_logits=True) for a in range(0, B, 16)]
-        with serve.PredictServer(eng, ("127.0.0.1", 0), beam_width=50) as srv, serve.PredictClient(srv.address, concurrency=3) as c:
+        with serve.PredictServer(eng, ("127.0.0.1", 0), beam_width=50) as srv, serve.PredictClient(srv.address, srv.authkey, concurrency=3) as c:
             assert c.signature()["max_batch"] == 16
             out = c.predict(x, ln)                                # 31 rows: two engine batches behind one request
             futs = [c.predict_future(x[i:i + 5], ln[i:i + 5], want_logits=True) for i in range(0, 30, 5)]

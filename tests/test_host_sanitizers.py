@@ -1,7 +1,7 @@
 """The host-side C++ of the C ABI (chiron_assemble, chiron_parse_signal_text) under AddressSanitizer and
 UndefinedBehaviorSanitizer (the reference has no sanitizer coverage; its Python cannot overrun a
-buffer, this C++ can), plus a randomized differential test of the native consensus vote against the Python form of
-easy_assembler.py:302-335 / :393-432."""
+buffer, this C++ can), plus randomized differential tests of the native displacement kernels and consensus vote against
+oracle/assembly_oracle.py (whose `simple` kernel runs the real difflib.SequenceMatcher)."""
 import os
 import subprocess
 
@@ -45,17 +45,47 @@ def _random_case(rng, related):
     return segs
 
 
-@pytest.mark.parametrize("kernal", ["glue", "stick"])
-def test_native_vote_equals_python_form_on_random_segments(built, kernal):
+@pytest.mark.parametrize("kernal", ["glue", "stick", "simple"])
+def test_native_vote_equals_the_oracle_on_random_segments(built, kernal):
     """bit-exact: the vote is integer counts (float64 holders) and per-base sums of per-segment qualities"""
-    rng = np.random.RandomState(31 if kernal == "glue" else 32)
+    from oracle import assembly_oracle as ao
+    rng = np.random.RandomState({"glue": 31, "stick": 32, "simple": 33}[kernal])
+    jr = 0.975 if kernal != "simple" else 0.075
     for it in range(400):
         segs = _random_case(rng, related=bool(it & 1))
         qs = rng.uniform(0, 20, size=(len(segs), 1))
-        want = assembly._python_assembly(segs, None, 0.975, 0.2, kernal)
-        got = assembly.simple_assembly(segs, 0.975, kernal=kernal)
+        want, _ = ao.vote(segs, None, jr, 0.2, kernal)
+        got = assembly.simple_assembly(segs, jr, kernal=kernal)
         assert got.shape == want.shape and np.array_equal(got, want), (it, segs)
-        wc, wq = assembly._python_assembly(segs, qs, 0.975, 0.2, kernal)
-        gc, gq = assembly.simple_assembly_qs(segs, qs, 0.975, kernal=kernal)
+        wc, wq = ao.vote(segs, qs, jr, 0.2, kernal)
+        gc, gq = assembly.simple_assembly_qs(segs, qs, jr, kernal=kernal)
         assert np.array_equal(gc, wc), (it, segs)
         np.testing.assert_allclose(gq, wq, rtol=1e-13, atol=0)
+
+
+def test_native_matching_blocks_equal_difflib(built):
+    """chiron_overlap_displacement(simple) against difflib on the shapes that exercise its corners: short and long
+    segments, unrelated / overlapping / identical / shifted pairs, and prev >= 200 bases, where difflib's autojunk drops
+    every base from its index (each of A, C, G, T is "popular") and matches only grow from rectangle corners."""
+    from oracle import assembly_oracle as ao
+    rng = np.random.RandomState(41)
+    pairs = [("ACGT", "ACGT"), ("A", "A"), ("A", "C"), ("ACGTACGT", "TTTT"), ("AAAA", "AAAAAAAA"), ("GATTACA", "TACAGATTACA")]
+    for it in range(1500):
+        genome = "".join(rng.choice(list("ACGT"), size=700))
+        la, lb = (int(rng.randint(1, 60)), int(rng.randint(1, 60))) if it % 3 else (int(rng.randint(150, 320)), int(rng.randint(180, 330)))
+        start = int(rng.randint(0, 300))
+        prev = genome[start:start + lb]
+        shift = int(rng.randint(-10, lb + 5))
+        cur = list(genome[max(0, start + shift):max(0, start + shift) + la]) or ["A"]
+        for i in range(len(cur)):
+            if rng.rand() < 0.08:
+                cur[i] = "ACGT"[rng.randint(4)]
+        if rng.rand() < 0.1:
+            del cur[len(cur) // 2:len(cur) // 2 + 2]
+        pairs.append(("".join(cur) or "A", prev))
+    for cur, prev in pairs:
+        for jr in (0.075, 0.5, 0.975):
+            want = ao.simple_displacement(cur, prev, 0.2, jr)
+            got = assembly.simple_assembly_kernal(cur, prev, 0.2, jr)
+            assert got[0] == want[0], (cur, prev, jr, got, want)
+            assert abs(got[1] - want[1]) <= 1e-12 * max(1.0, abs(want[1]))
