@@ -46,6 +46,11 @@ class Decoded(C.Structure):
                 ("batch", C.c_int32), ("T", C.c_int32)]
 
 
+class EngineSizes(C.Structure):
+    _fields_ = [("T", C.c_int32), ("ratio", C.c_double), ("largest_tensor_bytes", C.c_uint64), ("tensor_limit_bytes", C.c_uint64),
+                ("slot_bytes", C.c_uint64), ("total_bytes", C.c_uint64)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("total_ms", C.c_double), ("launches", C.c_int64),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -57,6 +62,7 @@ SYMBOLS = [
     ("chiron_engine_create", C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_size_t, C.POINTER(EngineOpts),
                                        C.POINTER(C.c_void_p)]),
     ("chiron_engine_destroy", None, [C.c_void_p]),
+    ("chiron_engine_plan", C.c_int, [C.POINTER(ModelDesc), C.POINTER(EngineOpts), C.POINTER(EngineSizes)]),
     ("chiron_engine_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("chiron_engine_submit", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_uint32]),
@@ -73,6 +79,7 @@ SYMBOLS = [
                                   C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     ("chiron_overlap_displacement", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
                                               C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    ("chiron_crc32c", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("chiron_last_error", C.c_char_p, []),
     ("chiron_abi_version", C.c_int32, []),
 ]

@@ -278,3 +278,36 @@ extern "C" chiron_status chiron_parse_signal_text(const char* text, size_t len, 
   *n_out = n;
   return CHIRON_OK;
 }
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8: what TF's tensor bundle stores per tensor
+// (BundleEntryProto.crc32c, masked; tensor_bundle.cc checks it on restore, chiron_amd/tf_bundle.py does the same).
+extern "C" chiron_status chiron_crc32c(const void* data, size_t len, uint32_t* out) {
+  if ((!data && len) || !out) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_crc32c: null argument");
+  static uint32_t table[8][256];
+  static bool ready = false;
+  if (!ready) {   // idempotent: concurrent first calls write identical values
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+      table[0][i] = c;
+    }
+    for (int k = 1; k < 8; ++k)
+      for (uint32_t i = 0; i < 256; ++i) table[k][i] = table[0][table[k - 1][i] & 0xFF] ^ (table[k - 1][i] >> 8);
+    ready = true;
+  }
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  uint32_t crc = 0xFFFFFFFFu;
+  while (len >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= crc;
+    crc = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+          table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    p += 8;
+    len -= 8;
+  }
+  while (len--) crc = table[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+  *out = crc ^ 0xFFFFFFFFu;
+  return CHIRON_OK;
+}

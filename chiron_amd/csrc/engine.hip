@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -133,7 +135,7 @@ struct BlockPlan {
   float *lift_a = nullptr, *lift_b = nullptr;  // lift: conv2a folded scale/shift
   float* res_a = nullptr;                      // lift: branch1 folded scale
   // lift, population BN: conv2a + conv2b as a piecewise-linear table of the signal value (pwl.hip)
-  float *pwl_bp = nullptr, *pwl_tab = nullptr, *pwl_shift = nullptr;
+  float *pwl_bp = nullptr, *pwl_ref = nullptr, *pwl_tab = nullptr, *pwl_shift = nullptr;
   int pwl_nbp = 0;
   ConvGemmPlan ga, gb, gc;                     // conv2a (non-lift), conv2b, conv2c(+conv1)
   // bn_mode = batch (cnn.py:166-188): the GEMM weights above are raw, gc holds conv2c alone, g1 the 1x1 branch1 conv;
@@ -186,7 +188,17 @@ struct Slot {
   float* h_prob = nullptr;
   float* h_logits = nullptr;
   // state of the in-flight batch
-  bool busy = false;
+  // 0 = idle, 1 = a batch is in flight (between a successful submit / decode and its collect).  Atomic: submit and
+  // collect of one slot may come from different threads (one producer, one consumer per engine; include/chiron_amd.h).
+  struct State {
+    std::atomic<int> v{0};
+    State() {}
+    State(const State& o) : v(o.v.load()) {}
+    State& operator=(const State& o) {
+      v.store(o.v.load());
+      return *this;
+    }
+  } state;
   int batch = 0;
   uint32_t flags = 0;
   const float* sig_used = nullptr;
@@ -408,24 +420,30 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
         // s -> -inf: a channel is active iff a < 0, or a == 0 and b > 0
         for (int c = 0; c < co; ++c)
           if (la[c] < 0.f || (la[c] == 0.f && lb[c] > 0.f)) toggle(c, 1.0);
-        std::vector<float> tab((size_t)(nb + 1) * kk * co * 2), bpf(std::max(nb, 1), 0.f);
+        std::vector<float> tab((size_t)(nb + 1) * kk * co * 2), bpf(std::max(nb, 1), 0.f), reff(nb + 1, 0.f);
+        for (int iv = 0; iv < nb; ++iv) bpf[iv] = (float)brk[iv].first;   // may round to +-inf: such a breakpoint is simply never crossed
         for (int iv = 0; iv <= nb; ++iv) {
           if (iv > 0) {
             const int c = brk[iv - 1].second;
             toggle(c, la[c] > 0.f ? 1.0 : -1.0);  // crossing its breakpoint upwards switches a channel on (a > 0) or off (a < 0)
-            bpf[iv - 1] = (float)brk[iv - 1].first;
           }
-          // value at the interval's reference point (its lower breakpoint; the first breakpoint for the interval below it)
-          // instead of the intercept: alpha*(s - ref) + f(ref) has no cancellation between alpha*s and beta
-          const double ref = nb > 0 ? (double)(float)brk[std::max(iv - 1, 0)].first : 0.0;
+          // The table stores the slope and the value at a reference point of the interval, f = alpha*(s - ref) + f(ref).
+          // ref = the point of the interval nearest to 0 (0 itself when the interval contains it): |s - ref| <= |s| for
+          // every s the interval can receive, so a breakpoint far outside the signal range (a near-dead channel: tiny
+          // folded scale, breakpoint at -1e6 or beyond float range) never makes alpha*(s - ref) cancel against f(ref).
+          const double lower = iv > 0 ? (double)bpf[iv - 1] : -(double)INFINITY, upper = iv < nb ? (double)bpf[iv] : (double)INFINITY;
+          double ref = std::min(std::max(0.0, lower), upper);
+          ref = std::min(std::max(ref, -(double)FLT_MAX), (double)FLT_MAX);
+          reff[iv] = (float)ref;
           for (size_t i = 0; i < (size_t)kk * co; ++i) {
             tab[((size_t)iv * kk * co + i) * 2] = (float)al[i];
-            tab[((size_t)iv * kk * co + i) * 2 + 1] = (float)(al[i] * ref + be[i]);
+            tab[((size_t)iv * kk * co + i) * 2 + 1] = (float)(al[i] * (double)reff[iv] + be[i]);
           }
         }
         std::vector<float> sh2(f2b.sh.begin(), f2b.sh.begin() + co);
         bp.pwl_nbp = nb;
         if ((st = dev_upload(e, &bp.pwl_bp, bpf))) return st;
+        if ((st = dev_upload(e, &bp.pwl_ref, reff))) return st;
         if ((st = dev_upload(e, &bp.pwl_tab, tab))) return st;
         if ((st = dev_upload(e, &bp.pwl_shift, sh2))) return st;
       }
@@ -566,6 +584,66 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
   return CHIRON_OK;
 }
 
+// ---- sizes of an engine, computable without a GPU: the frame count, the largest tensor a kernel addresses with a
+// 32-bit byte offset, the device memory of a slot.  chiron_engine_create refuses what this refuses.
+// Limits (kernels.h / gemm.hip): the DMA GEMMs read their A operand through a raw-buffer descriptor with
+// num_records = 0xFFFE0000 and 32-bit per-lane byte offsets, and the recurrence writes lasth through 32-bit byte
+// offsets, so every activation tensor and every lasth tensor must stay below 0xFFFE0000 bytes; row counts are ints.
+static const uint64_t TENSOR_LIMIT = 0xFFFE0000ull;
+
+static chiron_status plan_sizes(const chiron_model_desc* d, const chiron_engine_opts* o, chiron_engine_sizes* out) {
+  chiron_status st = validate_desc(d);
+  if (st) return st;
+  if (!o) return fail(CHIRON_ERR_INVALID, "null opts");
+  if (o->max_batch < 1 || o->segment_len < 1) return fail(CHIRON_ERR_INVALID, "max_batch/segment_len must be positive");
+  if (o->dtype != CHIRON_F32 && o->dtype != CHIRON_F16 && o->dtype != CHIRON_F32_SPLIT)
+    return fail(CHIRON_ERR_INVALID, "dtype %d unknown (0 = f32, 1 = f16, 2 = f32 as hi/lo half pairs)", o->dtype);
+  if (o->max_beam < 0) return fail(CHIRON_ERR_INVALID, "max_beam %d", o->max_beam);
+  const bool f16 = o->dtype == CHIRON_F16, split = o->dtype == CHIRON_F32_SPLIT, bn_batch = d->bn_mode == CHIRON_BN_BATCH;
+  const uint64_t B = (uint64_t)o->max_batch, BP = (uint64_t)roundup(o->max_batch, 16), L = (uint64_t)o->segment_len, H = d->hidden, K = d->classes;
+  int t = o->segment_len, left = 0;
+  uint64_t tmax = 0, cmax = 0;
+  if (d->stem_k > 0) same_pad(t, d->stem_k, d->stem_stride, &t, &left);
+  for (int i = 0; i < d->n_blocks; ++i) {
+    tmax = std::max<uint64_t>(tmax, (uint64_t)t);
+    same_pad(t, d->blocks[i].k, d->blocks[i].stride, &t, &left);
+    tmax = std::max<uint64_t>(tmax, (uint64_t)t);
+    cmax = std::max<uint64_t>(cmax, (uint64_t)d->blocks[i].out_channels);
+  }
+  const uint64_t T = (uint64_t)t;
+  const uint64_t lasth_ld = !split ? 2 * H : d->rnn_kind == CHIRON_RNN_MULTI ? 2 * (uint64_t)roundup(d->hidden, 32) : (uint64_t)roundup(2 * d->hidden, 32);
+  const uint64_t act = B * tmax * cmax * (f16 ? 2 : 4), lasth = T * BP * lasth_ld * 4, z = T * BP * 2 * 4 * H * 4;
+  if (B * tmax >= (1ull << 31) || T * BP >= (1ull << 31))
+    return fail(CHIRON_ERR_OVERFLOW, "max_batch %d x %llu frames does not fit the kernels' int row index", o->max_batch, (unsigned long long)tmax);
+  if (act > TENSOR_LIMIT)
+    return fail(CHIRON_ERR_OVERFLOW, "max_batch %d: an activation tensor [%d x %llu x %llu] needs %llu bytes, the kernels address at most %llu "
+                "per tensor (about %llu windows at this segment length and dtype): use a smaller max_batch",
+                o->max_batch, o->max_batch, (unsigned long long)tmax, (unsigned long long)cmax, (unsigned long long)act,
+                (unsigned long long)TENSOR_LIMIT, (unsigned long long)(TENSOR_LIMIT / (tmax * cmax * (f16 ? 2 : 4))));
+  if (T * BP * lasth_ld * (f16 ? 2 : 4) > TENSOR_LIMIT)   // the f16 engine keeps lasth as halves (the allocation stays 4 bytes per element)
+    return fail(CHIRON_ERR_OVERFLOW, "max_batch %d: the recurrent output [%llu x %llu x %llu] needs %llu bytes, the kernels address at most %llu per tensor",
+                o->max_batch, (unsigned long long)T, (unsigned long long)BP, (unsigned long long)lasth_ld, (unsigned long long)lasth,
+                (unsigned long long)TENSOR_LIMIT);
+  uint64_t slot = B * L * 4 + BP * 4 + (bn_batch ? 5 : 3) * act + (bn_batch ? 2 * 2 * cmax * 8 : 0) + z + 2 * lasth + (split ? T * BP * 2 * H * 4 : 0);
+  slot += B * T * K * 4 + B * T + 3 * B * 4 + (B + 1) * 8 + B * T * 16 + B * T * 8 + 3 * 8;
+  if (o->max_beam > 0) slot += beam_workspace_bytes((int)B, (int)T, o->max_beam);
+  if (out) {
+    out->T = (int32_t)T;
+    out->ratio = (double)o->segment_len / (double)T;
+    out->largest_tensor_bytes = std::max(act, T * BP * lasth_ld * (f16 ? 2 : 4));
+    out->tensor_limit_bytes = TENSOR_LIMIT;
+    out->slot_bytes = slot;
+    out->total_bytes = slot * (uint64_t)std::max(1, o->n_slots);
+  }
+  return CHIRON_OK;
+}
+
+extern "C" chiron_status chiron_engine_plan(const chiron_model_desc* desc, const chiron_engine_opts* opts, chiron_engine_sizes* out) {
+  if (!out) return fail(CHIRON_ERR_INVALID, "null out");
+  memset(out, 0, sizeof(*out));
+  return plan_sizes(desc, opts, out);
+}
+
 static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   const size_t B = e->maxB, BP = e->BP, L = e->L, T = e->T, H = e->H, K = e->K;
@@ -620,9 +698,10 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   size_t want = 0;
   chiron_weights_size(desc, &want);
   if (want != n_floats) return fail(CHIRON_ERR_INVALID, "weight blob has %zu floats, descriptor needs %zu", n_floats, want);
-  if (opts->max_batch < 1 || opts->segment_len < 1) return fail(CHIRON_ERR_INVALID, "max_batch/segment_len must be positive");
-  if (opts->dtype != CHIRON_F32 && opts->dtype != CHIRON_F16 && opts->dtype != CHIRON_F32_SPLIT)
-    return fail(CHIRON_ERR_INVALID, "dtype %d unknown (0 = f32, 1 = f16, 2 = f32 as hi/lo half pairs)", opts->dtype);
+  {
+    chiron_engine_sizes sz;
+    if ((st = plan_sizes(desc, opts, &sz))) return st;   // argument checks and the 32-bit addressing limits, before any GPU call
+  }
   if (desc->hidden != 100) return fail(CHIRON_ERR_INVALID, "hidden=%d: the recurrence kernel is built for hidden=100 (both shipped models)", desc->hidden);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CHIRON_ERR_DEVICE, "no HIP device visible: libchiron_amd has no CPU fallback");
@@ -864,7 +943,7 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       if (b.pwl_tab != nullptr) {
         // conv2a + conv2b in one memory-bound pass over a piecewise-linear table of the signal value (pwl.hip)
         PwlConvParams q;
-        q.sig = sig, q.bp = b.pwl_bp, q.tab = reinterpret_cast<const float2*>(b.pwl_tab), q.shift = b.pwl_shift, q.out = bufB;
+        q.sig = sig, q.bp = b.pwl_bp, q.ref = b.pwl_ref, q.tab = reinterpret_cast<const float2*>(b.pwl_tab), q.shift = b.pwl_shift, q.out = bufB;
         q.B = B, q.L = e->L, q.T_out = b.t_out, q.k = b.k, q.stride = b.stride, q.left = b.left, q.C = b.c, q.nbp = b.pwl_nbp;
         q.fmt = e->f16 ? 1 : e->split ? 2 : 0;
         Prof pr(e, s, PN_PWL, 2.0 * B * b.t_out * (double)b.k * b.c, 4.0 * B * e->L + (e->f16 ? 2.0 : 4.0) * B * b.t_out * b.c);
@@ -1091,32 +1170,41 @@ extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, co
   if (beam_width < 0) return fail(CHIRON_ERR_INVALID, "beam_width %d", beam_width);
   if (beam_width > e->opts.max_beam) return fail(CHIRON_ERR_OVERFLOW, "beam_width %d exceeds max_beam %d given at create", beam_width, e->opts.max_beam);
   Slot* s = &e->slots[slot];
+  if (s->state.v.load(std::memory_order_acquire) != 0)
+    return fail(CHIRON_ERR_STATE, "slot %d still holds an uncollected batch: collect it before the next submit", slot);
   HIP_TRY(hipSetDevice(e->opts.device_id));
-  if (s->busy) HIP_TRY(hipStreamSynchronize(s->stream));
   const int B = batch;
-  const float* sig;
-  HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
-  if (flags & CHIRON_X_ON_DEVICE) {
-    sig = x;
-    HIP_TRY(hipMemcpyAsync(s->seq, seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
-  } else {
-    memcpy(s->h_sig, x, (size_t)B * e->L * 4);
-    memcpy(s->h_seq, seq_len, (size_t)B * 4);
-    HIP_TRY(hipMemcpyAsync(s->sig, s->h_sig, (size_t)B * e->L * 4, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->seq, s->h_seq, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
-    sig = s->sig;
-  }
-  if (!run_cnn(e, s, B, sig) || !run_rnn(e, s, B))
-    return fail(CHIRON_ERR_INVALID, "a GEMM of this topology has no kernel for the engine's dtype");
-
-  {
+  // Everything from here on puts work on the slot's stream that reads the slot's pinned staging buffers.  If any
+  // step fails the stream is drained before returning, so a later submit can never overwrite h_sig / h_seq under a
+  // copy that is still running; the slot stays idle.
+  auto enqueue = [&]() -> chiron_status {
+    const float* sig;
+    HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
+    if (flags & CHIRON_X_ON_DEVICE) {
+      sig = x;
+      HIP_TRY(hipMemcpyAsync(s->seq, seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
+    } else {
+      memcpy(s->h_sig, x, (size_t)B * e->L * 4);
+      memcpy(s->h_seq, seq_len, (size_t)B * 4);
+      HIP_TRY(hipMemcpyAsync(s->sig, s->h_sig, (size_t)B * e->L * 4, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(s->seq, s->h_seq, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
+      sig = s->sig;
+    }
+    if (!run_cnn(e, s, B, sig) || !run_rnn(e, s, B))
+      return fail(CHIRON_ERR_INVALID, "a GEMM of this topology has no kernel for the engine's dtype");
     chiron_status st = enqueue_decode(e, s, B, beam_width, flags);
     if (st) return st;
+    HIP_TRY(hipGetLastError());
+    return CHIRON_OK;
+  };
+  const chiron_status st = enqueue();
+  if (st) {
+    hipStreamSynchronize(s->stream);
+    return st;
   }
-  HIP_TRY(hipGetLastError());
-  s->busy = true;
   s->batch = B;
   s->flags = flags;
+  s->state.v.store(1, std::memory_order_release);
   return CHIRON_OK;
 }
 
@@ -1130,24 +1218,33 @@ extern "C" chiron_status chiron_engine_decode(chiron_engine* e, int32_t slot, co
   if (beam_width < 0) return fail(CHIRON_ERR_INVALID, "beam_width %d", beam_width);
   if (beam_width > e->opts.max_beam) return fail(CHIRON_ERR_OVERFLOW, "beam_width %d exceeds max_beam %d given at create", beam_width, e->opts.max_beam);
   Slot* s = &e->slots[slot];
+  if (s->state.v.load(std::memory_order_acquire) != 0)
+    return fail(CHIRON_ERR_STATE, "slot %d still holds an uncollected batch: collect it before the next decode", slot);
   HIP_TRY(hipSetDevice(e->opts.device_id));
-  if (s->busy) HIP_TRY(hipStreamSynchronize(s->stream));
   const size_t nlog = (size_t)batch * e->T * e->K * 4;
-  HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
-  const hipMemcpyKind kind = (flags & CHIRON_X_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  if (!(flags & CHIRON_X_ON_DEVICE)) {
-    memcpy(s->h_logits, logits, nlog);
-    memcpy(s->h_seq, seq_len, (size_t)batch * 4);
-    logits = s->h_logits;
-    seq_len = s->h_seq;
+  auto enqueue = [&]() -> chiron_status {
+    HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
+    const hipMemcpyKind kind = (flags & CHIRON_X_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const float* src = logits;
+    const int32_t* sl = seq_len;
+    if (!(flags & CHIRON_X_ON_DEVICE)) {
+      memcpy(s->h_logits, logits, nlog);
+      memcpy(s->h_seq, seq_len, (size_t)batch * 4);
+      src = s->h_logits;
+      sl = s->h_seq;
+    }
+    HIP_TRY(hipMemcpyAsync(s->logits, src, nlog, kind, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->seq, sl, (size_t)batch * 4, kind, s->stream));
+    return enqueue_decode(e, s, batch, beam_width, flags & ~CHIRON_WANT_LOGITS);
+  };
+  const chiron_status st = enqueue();
+  if (st) {
+    hipStreamSynchronize(s->stream);
+    return st;
   }
-  HIP_TRY(hipMemcpyAsync(s->logits, logits, nlog, kind, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->seq, seq_len, (size_t)batch * 4, kind, s->stream));
-  chiron_status st = enqueue_decode(e, s, batch, beam_width, flags & ~CHIRON_WANT_LOGITS);
-  if (st) return st;
-  s->busy = true;
   s->batch = batch;
   s->flags = flags & ~CHIRON_WANT_LOGITS;
+  s->state.v.store(1, std::memory_order_release);
   return CHIRON_OK;
 }
 
@@ -1155,7 +1252,7 @@ extern "C" chiron_status chiron_engine_collect(chiron_engine* e, int32_t slot, c
   if (!e || !out) return fail(CHIRON_ERR_INVALID, "null engine/out");
   if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range", slot);
   Slot* s = &e->slots[slot];
-  if (!s->busy) return fail(CHIRON_ERR_STATE, "collect on slot %d without a submitted batch", slot);
+  if (s->state.v.load(std::memory_order_acquire) != 1) return fail(CHIRON_ERR_STATE, "collect on slot %d without a submitted batch", slot);
   HIP_TRY(hipSetDevice(e->opts.device_id));
   HIP_TRY(hipStreamSynchronize(s->stream));
   const int64_t nnz = s->h_meta[0];
@@ -1175,7 +1272,7 @@ extern "C" chiron_status chiron_engine_collect(chiron_engine* e, int32_t slot, c
   out->logits = (s->flags & CHIRON_WANT_LOGITS) ? s->h_logits : nullptr;
   out->batch = s->batch;
   out->T = e->T;
-  s->busy = false;
+  s->state.v.store(0, std::memory_order_release);
   return CHIRON_OK;
 }
 

@@ -108,7 +108,8 @@ void launch_split_convert(const float* src, void* dst, long rows, int cols, int 
 struct PwlConvParams {
   const float* sig;   // [B][L]
   const float* bp;    // [nbp] breakpoints of relu(s*a[c] + b[c]), ascending
-  const float2* tab;  // [nbp + 1][k][C] (alpha, f(ref)): f[tap][n](s) = alpha*(s - ref) + f(ref) on the interval, ref = its lower breakpoint
+  const float* ref;   // [nbp + 1] reference point of every interval (its point nearest to 0)
+  const float2* tab;  // [nbp + 1][k][C] (alpha, f(ref)): f[tap][n](s) = alpha*(s - ref) + f(ref) on the interval
   const float* shift; // [C] folded BN offset of conv2b
   void* out;          // [B*T_out][C] in the engine's activation format
   int B, L, T_out, k, stride, left, C, nbp;

@@ -6,8 +6,8 @@
 //     y[pos][n] = relu( sh[n] + sum_tap f[tap][n]( s[pos*stride + tap - left] ) ),
 //     f[tap][n](s) = sum_c W2b'[tap][c][n] * relu(s*a[c] + b[c]),
 // and each f is PIECEWISE LINEAR in s with at most C breakpoints s_c = -b[c]/a[c] (the same for every tap and n).
-// The engine tabulates, on the host and in float64, the slope alpha and the value f(ref) at the lower breakpoint ref of
-// every interval between consecutive breakpoints (f = alpha*(s - ref) + f(ref): no cancellation); this kernel finds the interval of each sample (binary search in LDS) and evaluates k taps
+// The engine tabulates, on the host and in float64, the slope alpha and the value f(ref) at a reference point ref of
+// every interval between consecutive breakpoints (f = alpha*(s - ref) + f(ref), ref = the interval's point nearest to 0: |s - ref| <= |s|, no cancellation); this kernel finds the interval of each sample (binary search in LDS) and evaluates k taps
 // with one 8-byte table read each -- instead of materialising a1 (450 MB) and running a K = k*256 GEMM over it
 // (173 GFLOP per batch for DNA_default).  Same function, re-associated: the table sums in float64, the result differs
 // from the GEMM form by fp32 rounding only (tests/test_gpu_parity.py holds the 1e-4 logit bound against the oracle).
@@ -24,6 +24,7 @@ constexpr int PWL_MAX_S = 512;    // samples a workgroup looks at: (PWL_TP - 1) 
 template <int FMT>
 __global__ __launch_bounds__(256) void pwl_conv_kernel(const PwlConvParams p) {
   __shared__ float bps[PWL_MAX_BP];
+  __shared__ float refs[PWL_MAX_BP + 1];
   __shared__ float ss[PWL_MAX_S];
   __shared__ int ks[PWL_MAX_S];
   const int tid = threadIdx.x;
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void pwl_conv_kernel(const PwlConvParams p) {
   const int t0 = (blockIdx.x - b * tiles_per_row) * PWL_TP;
   const int np = min(PWL_TP, p.T_out - t0);
   for (int i = tid; i < p.nbp; i += 256) bps[i] = p.bp[i];
+  for (int i = tid; i <= p.nbp; i += 256) refs[i] = p.ref[i];
   __syncthreads();
   const int nsamp = (np - 1) * p.stride + p.k;
   for (int i = tid; i < nsamp; i += 256) {
@@ -43,8 +45,8 @@ __global__ __launch_bounds__(256) void pwl_conv_kernel(const PwlConvParams p) {
       const int mid = (lo + hi) >> 1;
       if (bps[mid] < s) lo = mid + 1; else hi = mid;
     }
-    // the table holds f at the interval's reference point (its lower breakpoint; the first one for interval 0)
-    ss[i] = s - (p.nbp > 0 ? bps[max(lo - 1, 0)] : 0.f);
+    // the table holds f at the interval's reference point (the point of the interval nearest to 0, engine.hip)
+    ss[i] = s - refs[lo];
     ks[i] = valid ? lo : -1;
   }
   __syncthreads();

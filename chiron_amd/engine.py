@@ -21,6 +21,19 @@ def _is_torch_cuda(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and x.is_cuda
 
 
+_DTYPES = {"fp32": _lib.F32, "fp16": _lib.F16, "fp32-split": _lib.F32_SPLIT}
+
+
+def plan_sizes(spec, max_batch, segment_len, n_slots=1, dtype="fp32", max_beam=0):
+    """chiron_engine_plan: what an Engine of this shape would allocate, without a GPU.  Raises ChironError with status
+    ERR_OVERFLOW when a tensor would exceed what the kernels can address (the engine constructor refuses the same)."""
+    desc = spec.to_c()
+    opts = _lib.EngineOpts(0, max_batch, segment_len, n_slots, _DTYPES[dtype], max_beam)
+    out = _lib.EngineSizes()
+    _lib.check(_lib.load().chiron_engine_plan(C.byref(desc), C.byref(opts), C.byref(out)))
+    return {k: getattr(out, k) for k, _ in _lib.EngineSizes._fields_}
+
+
 class Engine(object):
     def __init__(self, spec, weights, max_batch, segment_len, device_id=0, n_slots=1, max_beam=0, dtype="fp32"):
         if not isinstance(spec, ModelSpec):
@@ -34,7 +47,7 @@ class Engine(object):
         if need.value != blob.size:
             raise ValueError("weight blob has %d floats, descriptor needs %d" % (blob.size, need.value))
         opts = _lib.EngineOpts(device_id, max_batch, segment_len, n_slots,
-                               {"fp32": _lib.F32, "fp16": _lib.F16, "fp32-split": _lib.F32_SPLIT}[dtype], max_beam)
+                               _DTYPES[dtype], max_beam)
         h = C.c_void_p()
         _lib.check(self._lib.chiron_engine_create(C.byref(desc), blob.ctypes.data_as(C.c_void_p), blob.size,
                                                   C.byref(opts), C.byref(h)))

@@ -50,47 +50,92 @@ class ModelSpec(object):
             return "BDLSTM_rnn/cell_%d/bidirectional_rnn/%s/lstm_cell/" % (layer, direction)
         return "BDGRU_rnn/%s/multi_rnn_cell/cell_%d/lstm_cell/" % (direction, layer)
 
+    BN_LEAVES = ("scale", "offset", "pop_mean", "pop_var")
+
     def bn_names(self, site):
+        """Checkpoint names of one BN site, in the order (scale, offset, pop_mean, pop_var); None = not stored."""
         if self.bn_mode == "population":      # cnn.py:125-163 naming (shipped checkpoints)
-            return [site + "_bn/scale", site + "_bn/offset", site + "_bn/pop_mean", site + "_bn/pop_var"]
-        leaf = site.split("/")[-1]            # cnn.py:181-186 naming (HEAD simple_global_bn)
+            return [site + "_bn/" + leaf for leaf in self.BN_LEAVES]
+        leaf = site.split("/")[-1]            # cnn.py:181-186 naming (HEAD simple_global_bn): no statistics are stored
         return [site + "_bn/" + leaf + "_bn_scale", site + "_bn/" + leaf + "_bn_offset", None, None]
 
-    def variables(self):
-        """Ordered {tf_variable_name: shape} in the blob order of include/chiron_amd.h."""
-        v = OrderedDict()
+    def _sites(self):
+        """(conv site, filter shape, has BN) in blob order"""
         if self.stem:
-            v[self.STEM_SITE + "/weights"] = (1, self.stem["k"], 1, self.stem["out"])
-            for nm in ("scale", "offset", "pop_mean", "pop_var"):
-                v[self.STEM_SITE + "_bn/" + nm] = (self.stem["out"],)
+            yield self.STEM_SITE, (1, self.stem["k"], 1, self.stem["out"]), True
         for b in self.blocks:
             n, ci, co, k = b["name"], b["in"], b["out"], b["k"]
-            for site, shape, has_bn in ((n + "/branch1/conv1", (1, 1, ci, co), b["i_bn"]),
-                                        (n + "/branch2/conv2a", (1, 1, ci, co), True),
-                                        (n + "/branch2/conv2b", (1, k, co, co), True),
-                                        (n + "/branch2/conv2c", (1, 1, co, co), True)):
-                v[site + "/weights"] = shape
-                if has_bn:
-                    for nm in ("scale", "offset", "pop_mean", "pop_var"):
-                        v[site + "_bn/" + nm] = (co,)
+            yield n + "/branch1/conv1", (1, 1, ci, co), bool(b["i_bn"])
+            yield n + "/branch2/conv2a", (1, 1, ci, co), True
+            yield n + "/branch2/conv2b", (1, k, co, co), True
+            yield n + "/branch2/conv2c", (1, 1, co, co), True
+
+    def _rnn_and_head(self):
         H = self.hidden
         for l in range(self.rnn_layers):
             for d in ("fw", "bw"):
-                v[self.lstm_scope(l, d) + "kernel"] = (self.lstm_in_width(l) + H, 4 * H)
-                v[self.lstm_scope(l, d) + "bias"] = (4 * H,)
-        v["rnn_fnn_layer/weights"] = (2, H)
-        v["rnn_fnn_layer/bias"] = (H,)
-        v["rnn_fnn_layer/weights_class"] = (H, self.classes)
-        v["rnn_fnn_layer/bias_class"] = (self.classes,)
+                yield self.lstm_scope(l, d) + "kernel", (self.lstm_in_width(l) + H, 4 * H)
+                yield self.lstm_scope(l, d) + "bias", (4 * H,)
+        yield "rnn_fnn_layer/weights", (2, H)
+        yield "rnn_fnn_layer/bias", (H,)
+        yield "rnn_fnn_layer/weights_class", (H, self.classes)
+        yield "rnn_fnn_layer/bias_class", (self.classes,)
+
+    def blob_layout(self):
+        """Ordered {canonical name: shape} = the weight blob of include/chiron_amd.h: every BN site has the four slots
+        scale, offset, pop_mean, pop_var whatever the BN mode (batch mode ignores the last two)."""
+        v = OrderedDict()
+        for site, shape, has_bn in self._sites():
+            v[site + "/weights"] = shape
+            if has_bn:
+                for leaf in self.BN_LEAVES:
+                    v[site + "_bn/" + leaf] = (shape[-1],)
+        v.update(self._rnn_and_head())
         return v
+
+    def variables(self):
+        """Ordered {tf_variable_name: shape} a checkpoint of this model holds (what load_model reads).  Population BN:
+        identical to blob_layout().  Batch BN (HEAD code): <site>_bn/<leaf>_bn_scale|_bn_offset, no statistics."""
+        v = OrderedDict()
+        for site, shape, has_bn in self._sites():
+            v[site + "/weights"] = shape
+            if has_bn:
+                for name in self.bn_names(site):
+                    if name is not None:
+                        v[name] = (shape[-1],)
+        v.update(self._rnn_and_head())
+        return v
+
+    def canonical_weights(self, weights):
+        """{checkpoint or canonical names -> arrays}  ==>  OrderedDict under the canonical names of blob_layout().
+        A HEAD-style (batch BN) checkpoint has no statistics: those slots are filled with mean 0 / variance 1."""
+        out = OrderedDict()
+        for site, shape, has_bn in self._sites():
+            out[site + "/weights"] = weights[site + "/weights"]
+            if not has_bn:
+                continue
+            for leaf, name in zip(self.BN_LEAVES, self.bn_names(site)):
+                canon = site + "_bn/" + leaf
+                if canon in weights:
+                    out[canon] = weights[canon]
+                elif name is not None and name in weights:
+                    out[canon] = weights[name]
+                elif name is None:
+                    out[canon] = np.full(shape[-1], 1.0 if leaf == "pop_var" else 0.0, dtype=np.float32)
+                else:
+                    raise KeyError("weight %r (or %r) missing" % (name, canon))
+        for name, _ in self._rnn_and_head():
+            if name not in weights:
+                raise KeyError("weight %r missing" % name)
+            out[name] = weights[name]
+        return out
 
     def pack(self, weights):
         """dict name -> array  ==>  flat float32 blob in ABI order."""
+        canon = self.canonical_weights(weights)
         parts = []
-        for name, shape in self.variables().items():
-            if name not in weights:
-                raise KeyError("weight %r missing" % name)
-            a = np.asarray(weights[name], dtype=np.float32)
+        for name, shape in self.blob_layout().items():
+            a = np.asarray(canon[name], dtype=np.float32)
             if tuple(a.shape) != tuple(shape):
                 raise ValueError("weight %r has shape %s, expected %s" % (name, a.shape, shape))
             parts.append(a.ravel())
@@ -306,7 +351,7 @@ def synthetic_weights(spec, seed=1234, logit_gain=20.0, lstm_gain=3.0):
     w["rnn_fnn_layer/weights_class"] = (logit_gain * rng.normal(0, math.sqrt(2.0 / H), (H, spec.classes))).astype(np.float32)
     w["rnn_fnn_layer/bias_class"] = rng.normal(0, 0.1, spec.classes).astype(np.float32)
     # keep the variable order / set identical to the spec's contract
-    ordered = OrderedDict((k, w[k]) for k in spec.variables())
+    ordered = OrderedDict((k, w[k]) for k in spec.blob_layout())
     return ordered
 
 
@@ -340,7 +385,7 @@ def load_model(model_dir, allow_synthetic=False, seed=1234):
         shapes = {k: v["shape"] for k, v in entries.items() if k}
         spec = spec_from_variables(shapes)
         if os.path.exists(prefix + ".data-00000-of-00001"):
-            weights = tf_bundle.read_tensors(prefix, entries, list(spec.variables()))
+            weights = spec.canonical_weights(tf_bundle.read_tensors(prefix, entries, list(spec.variables())))
             return spec, weights, config
     else:
         spec = spec_from_config(config)

@@ -137,8 +137,26 @@ def read_index(index_path):
     return out
 
 
-def read_tensors(prefix, entries=None, names=None):
-    """Load `names` (default: all float32 entries) from <prefix>.data-00000-of-00001."""
+def crc32c(data):
+    """CRC-32C (Castagnoli) through the native library (chiron_crc32c, host code: no GPU involved)."""
+    import ctypes
+    from . import _lib
+    data = bytes(data)
+    out = ctypes.c_uint32()
+    _lib.check(_lib.load().chiron_crc32c(data, len(data), ctypes.byref(out)))
+    return out.value
+
+
+def masked_crc32c(data):
+    """TF's lib/hash/crc32c.h Mask(): rotate right by 15 and add a constant -- what BundleEntryProto.crc32c stores."""
+    c = crc32c(data)
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def read_tensors(prefix, entries=None, names=None, verify=True):
+    """Load `names` (default: all float32 entries) from <prefix>.data-00000-of-00001.  Every tensor's bytes are checked
+    against the masked CRC-32C its BundleEntryProto records (tensor_bundle.cc verifies the same on restore); a
+    mismatch raises IOError naming the variable."""
     if entries is None:
         entries = read_index(prefix + ".index")
     data_path = prefix + ".data-00000-of-00001"
@@ -158,5 +176,8 @@ def read_tensors(prefix, entries=None, names=None):
             raw = f.read(e["size"])
             if len(raw) != e["size"]:
                 raise IOError("%s is truncated at variable %r" % (data_path, name))
+            if verify and e["crc32c"] is not None and masked_crc32c(raw) != e["crc32c"]:
+                raise IOError("%s: checksum mismatch in variable %r (stored crc32c %08x): the checkpoint data is corrupt"
+                              % (data_path, name, e["crc32c"]))
             out[name] = np.frombuffer(raw, dtype=_NP[e["dtype"]]).reshape(e["shape"]).copy()
     return out

@@ -33,8 +33,8 @@ typedef enum {
   CHIRON_OK = 0,
   CHIRON_ERR_INVALID = 1,   /* bad argument / unsupported topology          */
   CHIRON_ERR_DEVICE = 2,    /* HIP runtime failure (no GPU, OOM, launch)     */
-  CHIRON_ERR_STATE = 3,     /* collect without submit, slot out of range ... */
-  CHIRON_ERR_OVERFLOW = 4   /* batch > max_batch, beam > limit               */
+  CHIRON_ERR_STATE = 3,     /* collect without submit, submit on a slot whose batch was not collected, slot out of range */
+  CHIRON_ERR_OVERFLOW = 4   /* batch > max_batch, beam > limit, a tensor beyond the kernels' 32-bit addressing */
 } chiron_status;
 
 /* One residual block, chiron/cnn.py:234-262 residual_layer():
@@ -122,12 +122,34 @@ chiron_status chiron_engine_create(const chiron_model_desc* desc, const float* w
                                    const chiron_engine_opts* opts, chiron_engine** out);
 void chiron_engine_destroy(chiron_engine* e);
 
+/* Sizes of the engine chiron_engine_create would build for (desc, opts), WITHOUT touching a GPU: frame count and ratio,
+ * the largest tensor the kernels address with 32-bit byte offsets against their limit, device bytes per slot and in
+ * total.  Returns CHIRON_ERR_OVERFLOW (with the largest max_batch that fits in the message) when a tensor would pass
+ * the limit -- e.g. fp32, segment_len 400, 256 channels: max_batch > 10485 -- and chiron_engine_create refuses the
+ * same configurations with the same status instead of reading zeros past the descriptor's range.                  */
+typedef struct {
+  int32_t T;
+  double ratio;
+  uint64_t largest_tensor_bytes;
+  uint64_t tensor_limit_bytes;
+  uint64_t slot_bytes;
+  uint64_t total_bytes;
+} chiron_engine_sizes;
+chiron_status chiron_engine_plan(const chiron_model_desc* desc, const chiron_engine_opts* opts, chiron_engine_sizes* out);
+
 /* T = number of logits frames per segment and ratio = segment_len / T
  * (chiron_model.py:151-152).                                                 */
 chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out_T, double* out_ratio);
 
-/* flags for submit */
-#define CHIRON_X_ON_DEVICE 1u   /* x / seq_len are device pointers on opts.device_id */
+/* Threading: one producer thread (submit / decode) and one consumer thread (collect) per engine may run concurrently;
+ * a slot alternates strictly submit -> collect (its state is an atomic, a second submit before the collect returns
+ * CHIRON_ERR_STATE and changes nothing).  Engines on different devices are independent.  A submit that fails after
+ * it has started to enqueue work drains the slot's stream before returning; the slot stays free.
+ *
+ * flags for submit */
+#define CHIRON_X_ON_DEVICE 1u   /* x / seq_len are device pointers on opts.device_id.  The slot streams are non-blocking
+                                   streams and are NOT ordered against the caller's: the buffers must be complete before
+                                   the call (synchronise the producing stream) and untouched until the collect          */
 #define CHIRON_WANT_PROB 2u     /* compute prob_logits = path_prob (chiron_eval.py:116-136, -e fastq) */
 #define CHIRON_WANT_LOGITS 4u   /* copy logits [B,T,K] back on collect                */
 #define CHIRON_NO_DECODE_COPY 8u /* leave decoded sparse tensor on the device (bench)  */
@@ -218,6 +240,11 @@ chiron_status chiron_overlap_displacement(const uint8_t* cur, int64_t n, const u
  * CHIRON_ERR_INVALID (the reference raises ValueError); more than cap values -> CHIRON_ERR_OVERFLOW.
  * Pure host code: callable without a GPU and from several threads at once (it does not touch Python). */
 chiron_status chiron_parse_signal_text(const char* text, size_t len, float* out, size_t cap, size_t* n_out);
+
+/* CRC-32C (Castagnoli) of a byte range: the checksum TF's tensor-bundle checkpoints record per tensor
+ * (BundleEntryProto.crc32c holds its masked form; tensor_bundle.cc verifies it in Saver.restore, chiron_eval.py:276).
+ * Host code, used by the checkpoint reader.                                                                        */
+chiron_status chiron_crc32c(const void* data, size_t len, uint32_t* out);
 
 const char* chiron_last_error(void);
 int32_t chiron_abi_version(void);

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol(built):
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "chiron_amd.h")).read()
-    declared = set(re.findall(r"\b(chiron_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(chiron_[a-z0-9_]+)\s*\(", header))
     declared -= {"chiron_status"}
     bound = {name for name, _, _ in _lib.SYMBOLS}
     assert declared == bound, "binding and header disagree: %s" % (declared ^ bound)
@@ -114,3 +114,35 @@ def test_stem_topology_contract(built):
     assert lib.chiron_weights_size(C.byref(d), C.byref(n)) == _lib.ERR_INVALID
     with pytest.raises(ValueError):
         ca.ModelSpec(ca.dna_default_spec().blocks, stem={"k": 9, "stride": 5, "out": 256})
+
+
+def test_engine_plan_sizes_and_addressing_limits(built):
+    """chiron_engine_plan (no GPU): frame counts, the per-slot footprint of BASELINE configs[1], and the refusal of a
+    max_batch whose activations / recurrent outputs pass the kernels' 32-bit addressing (0xFFFE0000 bytes per tensor)
+    -- fp32, segment 400, 256 channels: 10485 windows fit, 10486 do not; halves double that."""
+    from chiron_amd.engine import plan_sizes
+    dna, rna = ca.dna_default_spec(), ca.rna_default_spec()
+    p = plan_sizes(dna, 1100, 400, n_slots=3)
+    assert p["T"] == 400 and p["ratio"] == 1.0 and p["tensor_limit_bytes"] == 0xFFFE0000
+    assert p["largest_tensor_bytes"] == 1100 * 400 * 256 * 4
+    z, lasth, act = 400 * 1104 * 800 * 4, 400 * 1104 * 200 * 4, 1100 * 400 * 256 * 4
+    assert z + 2 * lasth + 3 * act < p["slot_bytes"] < z + 2 * lasth + 3 * act + 40e6 and p["total_bytes"] == 3 * p["slot_bytes"]
+    assert plan_sizes(rna, 400, 500)["T"] == 100 and plan_sizes(ca.rna_head_spec("rna_model3"), 8, 500)["ratio"] == 500 / 72
+    assert plan_sizes(dna, 1100, 400, max_beam=50)["slot_bytes"] > p["slot_bytes"] + 5e8
+    assert plan_sizes(dna, 10485, 400)["largest_tensor_bytes"] <= 0xFFFE0000
+    for kw in (dict(max_batch=10486, segment_len=400), dict(max_batch=30000, segment_len=400, dtype="fp16"),
+               dict(max_batch=1100, segment_len=4000), dict(max_batch=6000000, segment_len=400)):
+        with pytest.raises(_lib.ChironError) as ei:
+            plan_sizes(dna, **kw)
+        assert ei.value.status == _lib.ERR_OVERFLOW, kw
+    assert plan_sizes(dna, 20000, 400, dtype="fp16")["T"] == 400          # halves: twice the rows
+    with pytest.raises(_lib.ChironError) as ei:
+        plan_sizes(dna, 0, 400)
+    assert ei.value.status == _lib.ERR_INVALID
+    # the constructor path refuses before it looks for a GPU
+    lib = _lib.load()
+    d = dna.to_c()
+    o = _lib.EngineOpts(0, 10486, 400, 1, _lib.F32, 0)
+    blob = np.zeros(sum(int(np.prod(v)) for v in dna.variables().values()), np.float32)
+    h = C.c_void_p()
+    assert lib.chiron_engine_create(C.byref(d), blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(o), C.byref(h)) == _lib.ERR_OVERFLOW

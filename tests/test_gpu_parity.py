@@ -227,7 +227,13 @@ def test_first_conv_table_degenerate_channels(dna):
     of[6:10] = of[10]
     w["res_layer1/branch2/conv2a_bn/pop_mean"][6:10] = w["res_layer1/branch2/conv2a_bn/pop_mean"][10]
     w["res_layer1/branch2/conv2a_bn/pop_var"][6:10] = w["res_layer1/branch2/conv2a_bn/pop_var"][10]
-    sc[12] = 1e-12                    # breakpoint at ~ +-1e12
+    # near-dead channels: breakpoints -b/a far outside the signal range on BOTH sides (1e5 .. beyond float range), with
+    # the channel on or off over the whole signal range; the table must not lose the sample in alpha*(s - ref)
+    far = np.array([1e-12, -1e-12, 1e-5, -1e-5, 1e-30, -1e-30, 3e-38, -3e-38], dtype=np.float32)
+    sc[12:20] = far * np.sign(cw[12:20])
+    of[12:20] = [0.5, 0.5, -0.5, -0.5, 0.5, -0.5, -0.5, 0.5]
+    w["res_layer1/branch2/conv2a_bn/pop_mean"][12:20] = 0.0
+    from oracle import nn_oracle
     L, B = 400, 9
     x, ln = _windows(390 * (B - 1) + 77, L, 390, seed=91)
     with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
@@ -235,6 +241,12 @@ def test_first_conv_table_degenerate_channels(dna):
         res = eng.infer(x, sl, want_logits=True)
     cref = c_oracle.forward(x, sl, spec.to_dict(), spec.pack(w), 400)
     assert np.isfinite(res.logits).all() and np.abs(res.logits - cref).max() < TOL
+    ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+    assert np.abs(res.logits - ref).max() < 5e-5
+    # the folded breakpoints really are where the comment says
+    inv = sc[12:20] / np.sqrt(w["res_layer1/branch2/conv2a_bn/pop_var"][12:20] + 1e-5)
+    bpts = -(of[12:20].astype(np.float64)) / (cw[12:20].astype(np.float64) * inv)
+    assert (bpts < -1e4).sum() >= 3 and (bpts > 1e4).sum() >= 3 and np.abs(bpts).max() > 1e30
 
 
 def test_producer_and_consumer_threads_share_one_engine(dna):

@@ -68,3 +68,72 @@ def test_round_trip_through_a_written_bundle(tmp_path, spec_fn):
     open(data, "r+b").truncate(os.path.getsize(data) // 2)
     with pytest.raises(IOError):
         ca.load_model(d)
+
+
+def test_reader_verifies_the_stored_crc32c(tmp_path):
+    """BundleEntryProto.crc32c (SURVEY appendix C): one flipped byte in the data file is reported by variable name;
+    verify=False still reads it (forensics); the reader's CRC equals the writer's independent bytewise one."""
+    from chiron_amd import tf_bundle
+    rng = np.random.RandomState(2)
+    for n in (0, 1, 7, 8, 9, 4096 + 3):
+        raw = rng.bytes(n)
+        assert tf_bundle.crc32c(raw) == crc32c(raw)
+    assert tf_bundle.crc32c(b"123456789") == 0xE3069283
+    spec = ca.dna_default_spec()
+    w = ca.synthetic_weights(spec, seed=6)
+    prefix = os.path.join(str(tmp_path), "final.ckpt-1")
+    write_bundle(prefix, dict(w))
+    entries = tf_bundle.read_index(prefix + ".index")
+    victim = "res_layer2/branch2/conv2b/weights"
+    with open(prefix + ".data-00000-of-00001", "r+b") as f:
+        f.seek(entries[victim]["offset"] + 1234)
+        b = f.read(1)
+        f.seek(-1, 1)
+        f.write(bytes([b[0] ^ 0x40]))
+    with pytest.raises(IOError, match="checksum mismatch in variable 'res_layer2/branch2/conv2b/weights'"):
+        tf_bundle.read_tensors(prefix, entries, list(spec.variables()))
+    got = tf_bundle.read_tensors(prefix, entries, [victim], verify=False)[victim]
+    assert (got != w[victim]).sum() == 1
+    ok = tf_bundle.read_tensors(prefix, entries, [n for n in spec.variables() if n != victim])
+    assert all(np.array_equal(ok[k], w[k]) for k in ok)
+
+
+def test_head_style_batch_bn_checkpoint_loads(tmp_path):
+    """A model trained with HEAD's simple_global_bn (cnn.py:166-188) stores <site>_bn/<leaf>_bn_scale|_bn_offset and no
+    statistics (last paragraph).  load_model must recognise it (bn_mode = batch), read exactly those
+    names, and hand the engine a blob whose unused pop_mean / pop_var slots are 0 / 1."""
+    spec_b = ca.dna_default_spec(bn_mode="batch")
+    w = ca.synthetic_weights(ca.dna_default_spec(), seed=8)          # canonical names
+    tensors = {}
+    for name, a in w.items():
+        if name.endswith("_bn/pop_mean") or name.endswith("_bn/pop_var"):
+            continue
+        if name.endswith("_bn/scale") or name.endswith("_bn/offset"):
+            site, leaf = name.rsplit("_bn/", 1)
+            name = "%s_bn/%s_bn_%s" % (site, site.split("/")[-1], leaf)
+        tensors[name] = a
+    assert set(tensors) == set(spec_b.variables()) and len(tensors) == 68 - 20
+    d = str(tmp_path)
+    write_bundle(os.path.join(d, "model.ckpt-3"), tensors, extra_int32={"global_step": 3})
+    open(os.path.join(d, "checkpoint"), "w").write('model_checkpoint_path: "model.ckpt-3"\n')
+    json.dump({"cnn": {"model": "dna_model1"}, "rnn": {"layer_num": 3, "hidden_num": 100, "cell_type": "LSTM",
+                                                         "layer_type": "normal"}}, open(os.path.join(d, "model.json"), "w"))
+    spec2, w2, _ = ca.load_model(d)
+    assert spec2.bn_mode == "batch" and spec2.blocks == spec_b.blocks
+    assert list(w2) == list(spec_b.blob_layout()) == list(ca.dna_default_spec().variables())
+    site = "res_layer2/branch2/conv2b"
+    assert np.array_equal(w2[site + "_bn/scale"], w[site + "_bn/scale"]) and np.array_equal(w2[site + "_bn/offset"], w[site + "_bn/offset"])
+    assert np.all(w2[site + "_bn/pop_mean"] == 0) and np.all(w2[site + "_bn/pop_var"] == 1)
+    blob = spec2.pack(w2)
+    assert blob.size == spec_b.pack(w).size
+    # the oracle consumes the same canonical dict (batch statistics ignore the filled slots)
+    from oracle import nn_oracle
+    x = ca.synthetic_signal(1, 2 * 64, seed=1)[0].reshape(2, 64)
+    a, _ = nn_oracle.inference(x, [64, 64], spec2.to_dict(), w2, dtype=np.float64)
+    b, _ = nn_oracle.inference(x, [64, 64], spec_b.to_dict(), w, dtype=np.float64)
+    assert np.array_equal(a, b)
+    # HEAD names handed straight to pack() work too; a missing scale is reported by name
+    assert np.array_equal(spec_b.pack(tensors), blob)
+    del tensors["res_layer1/branch1/conv1_bn/conv1_bn_scale"]
+    with pytest.raises(KeyError, match="conv1_bn_scale"):
+        spec_b.pack(tensors)
