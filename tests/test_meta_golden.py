@@ -227,7 +227,8 @@ def test_oracle_reproduces_the_executed_graph_batch_statistics(meta):
 @pytest.mark.parametrize("model", ["dna", "rna"])
 def test_engine_logits_match_the_executed_graph(meta, model):
     """HIP engine at the graph's own shape (DNA 300 x 400, RNA 100 x 2000) against activations of the reference's node
-    list: every golden row within 1e-4 (north-star fp32 tolerance), every row's logits sum within 5e-3."""
+    list: every golden row within 1e-4 (north-star fp32 tolerance); every row's sum of T x 5 logits within 2e-2, i.e. a
+    mean deviation of 1e-5 per logit (the sums catch a wrong row anywhere in the batch, not rounding)."""
     spec, w, z, info = _case(meta, model)
     x = z["x"].astype(np.float32)
     sl = z["seq_len"].astype(np.int32)
@@ -237,8 +238,8 @@ def test_engine_logits_match_the_executed_graph(meta, model):
     lg = res.logits.astype(np.float64)
     err = np.abs(lg[z["rows"]] - z["logits_rows_population"]).max()
     assert err < 1e-4, err
-    assert np.abs(lg.sum(axis=(1, 2)) - z["logits_rowsum_population"]).max() < 5e-3
-    assert np.abs(np.abs(lg).sum(axis=(1, 2)) - z["logits_abssum_population"]).max() < 5e-3
+    assert np.abs(lg.sum(axis=(1, 2)) - z["logits_rowsum_population"]).max() < 2e-2
+    assert np.abs(np.abs(lg).sum(axis=(1, 2)) - z["logits_abssum_population"]).max() < 2e-2
 
 
 @pytest.mark.gpu
@@ -249,4 +250,4 @@ def test_engine_batch_statistics_match_the_executed_graph(meta):
         res = eng.infer(z["x"].astype(np.float32), z["seq_len"].astype(np.int32), want_logits=True)
     lg = res.logits.astype(np.float64)
     assert np.abs(lg[z["rows"]] - z["logits_rows_batch"]).max() < 1e-4
-    assert np.abs(lg.sum(axis=(1, 2)) - z["logits_rowsum_batch"]).max() < 5e-3
+    assert np.abs(lg.sum(axis=(1, 2)) - z["logits_rowsum_batch"]).max() < 2e-2
