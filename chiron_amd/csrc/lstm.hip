@@ -31,10 +31,14 @@ namespace chiron {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // h_{t-1} of one 4-row group in LDS, in the order the MFMA A operand wants it: lane (blk = lane>>2, row = lane&3)
-// keeps h[row][16q + blk], q = 0..7, in 8 consecutive floats (two ds_read_b128 per step).  The 4x4x1 MFMA for
-// k = 16q + blk then BROADCASTS block blk's A vector to all 16 blocks (cbsz = 4, abid = blk; semantics checked in
-// tools/ubench/mfma4x4_bcast.hip), so a wave reads 2 KB of h per step instead of 25.6 KB.
-constexpr int HG = 16 * 4 * 8;  // floats per group and buffer
+// keeps h[row][16q + blk], q = 0..6.  The 4x4x1 MFMA for k = 16q + blk then BROADCASTS block blk's A vector to all 16
+// blocks (cbsz = 4, abid = blk; semantics checked in tools/ubench/mfma4x4_bcast.hip), so a wave reads 2 KB of h per
+// step instead of 25.6 KB.  Layout [q][lane]: the tile of k-group q is 64 consecutive floats indexed by the READING
+// lane, so a read is lane-linear (seven 4-byte reads, paired by the compiler into ds_read2_b32) and the cell of
+// (row, unit = 16q + blk), which sits in lane row*16 + blk of wave q, writes float q*64 + blk*4 + row: the 64 writers
+// of a wave hit 64 different banks (the [lane][q] order of round 1 put them 8 floats apart: an 8-way conflict on
+// every write, SQ_LDS_BANK_CONFLICT 0.73 of the LDS cycles).
+constexpr int HG = 8 * 64;  // floats per group and buffer (q = 7 is never used: K = 100 < 112)
 
 // Gate math on the hardware exp2 / rcp.  The four pre-activations are scaled two at a time (v_pk_mul_f32) and the
 // "+ 1" of the four denominators added two at a time (v_pk_add_f32): every VALU instruction of the step is paid in
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
   const unsigned zgrp = p.ndir * zcols * 4;                 // floats between consecutive row groups
   const unsigned ostep = p.BP * outw;                            // floats between consecutive frames of the output
   const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
-  const int hw = ((lane & 15) * 4 + row) * 8 + wave;             // where this lane's cell writes h: blk = unit & 15, q = wave
+  const int hw = wave * 64 + (lane & 15) * 4 + row;              // where this lane's cell writes h: q = wave, blk = unit & 15
 
   float c[NG], hprev[NG];
 #pragma unroll
@@ -145,17 +149,12 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
     f32x4 acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* hb = hbuf + cur * (NG * HG) + lane * 8;
-    f32x4 hv0[NG];
-    float hv1[NG][3];
+    const float* hb = hbuf + cur * (NG * HG) + lane;
+    float hv[NG][7];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      hv0[g] = *reinterpret_cast<const f32x4*>(hb + g * HG);
-      const float2 t2 = *reinterpret_cast<const float2*>(hb + g * HG + 4);
-      hv1[g][0] = t2.x;
-      hv1[g][1] = t2.y;
-      hv1[g][2] = hb[g * HG + 6];
-    }
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int q = 0; q < 7; ++q) hv[g][q] = hb[g * HG + q * 64];
 #define CHIRON_MF(B)                                                                                       \
   if (16 * q + (B) < LSTM_K)                                                                                \
     acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq, w[(16 * q + (B)) % LSTM_K], acc[g], 4, B, 0);
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(con
     for (int q = 0; q < (LSTM_K + 15) / 16; ++q) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        const float hq = q < 4 ? hv0[g][q & 3] : hv1[g][(q - 4) % 3];
+        const float hq = hv[g][q];
         CHIRON_MF(0) CHIRON_MF(1) CHIRON_MF(2) CHIRON_MF(3) CHIRON_MF(4) CHIRON_MF(5) CHIRON_MF(6) CHIRON_MF(7)
         CHIRON_MF(8) CHIRON_MF(9) CHIRON_MF(10) CHIRON_MF(11) CHIRON_MF(12) CHIRON_MF(13) CHIRON_MF(14) CHIRON_MF(15)
       }
