@@ -51,31 +51,22 @@ def evaluation(args):
     FLAGS.idname = False
     FLAGS.delimiter = "\n"
     args.reverse_fast5 = args.mode == "rna"
-    # One process per GPU (torchrun / torch.distributed.run): reads shard per rank, results are
-    # gathered on the host; no collective on the data path.
-    import os
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        if torch.cuda.is_available():
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group("gloo")
-        FLAGS.device = local
-    rank = dist.get_rank() if dist is not None else 0
+    # One process per GPU (torchrun / torch.distributed.run): reads shard per rank -- extraction, basecalling and the
+    # result files -- and are gathered on the host; no collective on the data path.
+    from . import shard
+    dist, rank, world, device = shard.init_distributed()
+    if device is not None:
+        FLAGS.device = device
     if path.isdir(FLAGS.input):
-        if rank == 0:
-            extract(FLAGS)
-        if dist is not None:
-            dist.barrier()
-        FLAGS.input = FLAGS.output + "/raw/"
+        from .extract import list_fast5
+        if list_fast5(FLAGS.input, True):
+            extract(FLAGS, rank, world)
+            if dist is not None:
+                dist.barrier()
+            FLAGS.input = FLAGS.output + "/raw/"
+        # else: a folder of .signal files (what extraction would have produced) is basecalled in place
     if dist is None:
         return chiron_eval.run(args)
-    from . import shard
     out = shard.run_sharded(FLAGS, lambda fl, mine: chiron_eval.evaluation(fl, file_list=mine), dist)
     dist.destroy_process_group()
     return out

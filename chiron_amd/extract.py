@@ -61,8 +61,22 @@ def _wrapper(args):
     return n
 
 
-def extract(FLAGS):
-    """extract_sig_ref.py:31-90."""
+def list_fast5(root_folder, recursive=True, test_number=None):
+    """Every *.fast5 under root_folder, sorted by path (the reference walks in os.walk order, extract_sig_ref.py:62-79;
+    sorted here so that every rank of a sharded run sees the same list)."""
+    files = []
+    for dirpath, _, filenames in os.walk(root_folder):
+        files += [os.path.join(dirpath, fn) for fn in filenames if fn.endswith("fast5")]
+        if not recursive:
+            break
+    files.sort()
+    return files[:test_number] if test_number else files
+
+
+def extract(FLAGS, rank=0, world=1):
+    """extract_sig_ref.py:31-90.  In a sharded run (one process per GPU) every rank extracts its own share of the
+    file list, file k -> rank k mod world, with its own worker pool -- the counterpart of the reference's
+    Pool(cpu_count()) (:58-60, :81) spread over the ranks instead of serialised on rank 0."""
     root_folder, out_folder = FLAGS.input_dir, FLAGS.output_dir
     if not os.path.isdir(root_folder):
         raise IOError("Input directory does not found.")
@@ -72,18 +86,9 @@ def extract(FLAGS):
     FLAGS.log_folder = os.path.abspath(os.path.join(out_folder, "log"))
     for d in (FLAGS.raw_folder, FLAGS.ref_folder, FLAGS.log_folder):
         os.makedirs(d, exist_ok=True)
-    set_logger(os.path.join(FLAGS.log_folder, "extract.log"))
-    threads = FLAGS.threads if getattr(FLAGS, "threads", 0) else cpu_count()
-    files = []
-    for dirpath, _, filenames in os.walk(root_folder):
-        for fn in sorted(filenames):
-            if fn.endswith("fast5"):
-                files.append(os.path.join(dirpath, fn))
-        if not getattr(FLAGS, "recursive", True):
-            break
-    files.sort()
-    if getattr(FLAGS, "test_number", None):
-        files = files[:FLAGS.test_number]
+    set_logger(os.path.join(FLAGS.log_folder, "extract.log" if world == 1 else "extract.rank%d.log" % rank))
+    threads = FLAGS.threads if getattr(FLAGS, "threads", 0) else max(1, cpu_count() // max(world, 1))
+    files = list_fast5(root_folder, getattr(FLAGS, "recursive", True), getattr(FLAGS, "test_number", None))[rank::max(world, 1)]
     if threads > 1 and len(files) > 1:
         with Pool(min(threads, len(files))) as pool:
             counts = pool.map(_wrapper, [(f, FLAGS) for f in files])

@@ -5,6 +5,28 @@ the data path -- torch.distributed is used for the barrier only (backend nccl on
 import os
 
 
+def init_distributed():
+    """One process per GPU under torch.distributed.run: -> (dist or None, rank, world, device or None).  RCCL (backend
+    "nccl") when every rank has its own GPU; with CHIRON_SHARE_GPU=1 -- the self-test of the N > 1 path on a box with
+    one GPU -- all ranks use device 0 and gloo carries the barriers (two RCCL ranks cannot share a device).  Only
+    barriers ever go through it."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, 0, 1, None
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("CHIRON_SHARE_GPU") == "1"
+    if torch.cuda.is_available() and not share:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        device = local
+    else:
+        dist.init_process_group("gloo")
+        device = 0
+    return dist, dist.get_rank(), dist.get_world_size(), device
+
+
 def partition_reads(files, world_size, rank, sizes=None):
     """Deterministic partition of the (sorted) read list.  Without sizes: read k -> rank k mod G.
     With sizes (bytes or samples): greedy longest-first balancing, ties by name."""

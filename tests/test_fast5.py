@@ -90,3 +90,60 @@ def test_multi_read_fast5_extract_file_v2(tmp_path):
     assert len(out) == 3
     rna = extract.extract_file(p, mode="rna")
     assert np.array_equal(rna[0][1], reads[0][2][::-1]) and rna[0][3] == "id-0-abc" and out[2][2].startswith("@x")
+
+
+def test_all_five_example_fast5_reproduce_the_reference_raw_signals():
+    """BASELINE configs[0] input: chiron/example_data/DNA/read{1..5}.fast5.  The reference checked in what its own
+    extraction produced (output/raw/readN.signal); tests/golden/example_dna/raw_digest.json holds sample count, SHA-256
+    and ends of each.  The h5py-free reader must give exactly those samples for all five files."""
+    import hashlib
+    import json
+    ex = os.path.join(GOLDEN, "example_dna")
+    digest = json.load(open(os.path.join(ex, "raw_digest.json")))
+    assert sorted(digest) == ["read%d" % i for i in range(1, 6)]
+    total_windows = 0
+    for name, d in digest.items():
+        recs = fast5.read_fast5(os.path.join(ex, name + ".fast5"))
+        assert len(recs) == 1
+        sig = np.asarray(recs[0]["signal"])
+        assert sig.dtype == np.int16 and sig.size == d["samples"]
+        assert sig[:5].tolist() == d["head"] and sig[-5:].tolist() == d["tail"]
+        assert hashlib.sha256(sig.astype("<i2").tobytes()).hexdigest() == d["sha256_int16le"]
+        ds = signal_io.read_data_for_eval(os.path.join(ex, name + ".fast5"), 0, 390, 400)
+        assert ds.reads_n == d["windows_L400_J390"]
+        total_windows += ds.reads_n
+    assert total_windows == 2688              # SURVEY 8(d): 2688 windows -> 27 batches of 100, the last wrap-padded by 12
+
+
+def test_extraction_shards_across_ranks(tmp_path):
+    """Sharded `chiron call` (one process per GPU): rank r extracts files r, r + world, ... of the sorted list with its
+    own pool; together the ranks produce exactly what a single process does (extract_sig_ref.py:58-60,81 spread over
+    ranks).  test_number cuts the GLOBAL list before sharding."""
+    import filecmp
+    import shutil
+    from h5_writer import write_multi_read_fast5
+    inp = tmp_path / "in"
+    (inp / "deep").mkdir(parents=True)
+    rng = np.random.RandomState(9)
+    for k in range(7):
+        reads = [("read_%d" % k, "id%d" % k, rng.randint(200, 1000, size=3000 + 17 * k).astype(np.int16), None)]
+        write_multi_read_fast5(str((inp / "deep" if k % 3 == 0 else inp) / ("f%02d.fast5" % k)), reads, chunk=1024 if k % 2 else None)
+    shutil.copy(F5, str(inp / "z_example.fast5"))
+
+    def flags(out, test_number=None):
+        import argparse                       # a Namespace like the CLI's: it travels to the pool workers
+        return argparse.Namespace(input_dir=str(inp), output_dir=str(out), mode="dna", unit=False, recursive=True, idname=False,
+                                  delimiter="\n", threads=2, test_number=test_number)
+    one = flags(tmp_path / "one")
+    assert extract.extract(one) == 8
+    two = tmp_path / "two"
+    counts = [extract.extract(flags(two), rank=r, world=2) for r in range(2)]
+    assert sum(counts) == 8 and min(counts) == 4
+    a, b = sorted(os.listdir(str(tmp_path / "one" / "raw"))), sorted(os.listdir(str(two / "raw")))
+    assert a == b and len(a) == 8
+    for n in a:
+        assert filecmp.cmp(str(tmp_path / "one" / "raw" / n), str(two / "raw" / n), shallow=False)
+    assert sorted(os.listdir(str(two / "log"))) == ["extract.rank0.log", "extract.rank1.log"]
+    three = tmp_path / "three"
+    assert sum(extract.extract(flags(three, test_number=3), rank=r, world=2) for r in range(2)) == 3
+    assert len(extract.list_fast5(str(inp), True)) == 8 and len(extract.list_fast5(str(inp), False)) == 5

@@ -681,28 +681,68 @@ def test_predict_signature_served_from_the_engine(dna):
 
 
 def test_chiron_call_cli_on_fast5_folder(tmp_path):
-    """BASELINE configs[0] plumbing: `chiron call` on a folder of fast5 files with model/DNA_default,
-    batch=100, greedy.  The trained weights are stripped from the reference tree, so the CLI runs with
-    --synthetic-weights (exact checkpoint shapes from the shipped .index)."""
+    """BASELINE configs[0] as written: `chiron call` on chiron/example_data/DNA -- all five example fast5 -- with
+    model/DNA_default, batch=100, greedy.  The trained weights are stripped from the reference tree, so the CLI runs
+    with --synthetic-weights (exact checkpoint shapes from the shipped .index): what is checked is the whole plumbing
+    (extraction == the reference's raw signals, 2688 windows in 27 batches with a wrap-padded tail, one
+    result / segments / meta file per read), and the output against the oracle decode of the engine's own logits."""
+    import hashlib
+    import json
     import shutil
-    from chiron_amd import entry, signal_io
+    from chiron_amd import assembly, entry, signal_io, eval as ce
+    from oracle import ctc_oracle
+    ex = os.path.join(GOLDEN, "example_dna")
+    digest = json.load(open(os.path.join(ex, "raw_digest.json")))
     inp = tmp_path / "fast5"
     inp.mkdir()
-    shutil.copy(os.path.join(GOLDEN, "example_dna", "read1.fast5"), str(inp / "read1.fast5"))
+    for name in digest:
+        shutil.copy(os.path.join(ex, name + ".fast5"), str(inp / (name + ".fast5")))
     out = str(tmp_path / "out")
     model = os.path.join(os.path.dirname(os.path.abspath(ca.__file__)), "model", "DNA_default")
     entry.main(["call", "-i", str(inp), "-o", out, "-m", model, "-p", "dna-pre", "-b", "100", "--beam", "0",
                 "--synthetic-weights"])
-    # extract step reproduced the reference's raw signal file content
-    assert np.array_equal(signal_io.read_signal(os.path.join(out, "raw", "read1.signal")),
-                          signal_io.read_signal(os.path.join(GOLDEN, "example_dna", "raw", "read1.signal")))
-    fq = open(os.path.join(out, "result", "read1.fastq")).read().split("\n")
-    assert fq[0] == "@read1" and fq[2] == "+" and len(fq[1]) == len(fq[3]) > 0 and set(fq[1]) <= set("ACGT")
-    meta = open(os.path.join(out, "meta", "read1.meta")).read().split("\n")
-    assert meta[3].split()[1:4] == ["100", "400", "390"]
+    spec, w, _ = ca.load_model(model, allow_synthetic=True)
+    with ca.Engine(spec, w, max_batch=100, segment_len=400) as eng:
+        for name, d in digest.items():
+            # extract step reproduced the reference's raw signal
+            sig = signal_io.read_signal(os.path.join(out, "raw", name + ".signal"))
+            assert sig.size == d["samples"] and hashlib.sha256(sig.astype("<i2").tobytes()).hexdigest() == d["sha256_int16le"]
+            fq = open(os.path.join(out, "result", name + ".fastq")).read().split("\n")
+            assert fq[0] == "@" + name and fq[2] == "+" and len(fq[1]) == len(fq[3]) > 0 and set(fq[1]) <= set("ACGT")
+            seg = open(os.path.join(out, "segments", name + ".fastq")).read().split("\n")
+            meta = open(os.path.join(out, "meta", name + ".meta")).read().split("\n")
+            assert meta[3].split() == [str(len(fq[1])), "100", "400", "390", "0"]
+            # the read's consensus == oracle greedy decode of the engine's logits + the glue vote, whatever batches
+            # (shared with neighbouring reads, wrap-padded at the end) its windows travelled in
+            ds = signal_io.read_data_for_eval(os.path.join(out, "raw", name + ".signal"), 0, 390, 400)
+            logits = np.concatenate([eng.infer(ds.event[i:i + 100], ca.seq_len_for_engine(ds.event_length[i:i + 100], 1.0),
+                                               want_logits=True).logits for i in range(0, ds.reads_n, 100)])
+            rows, _ = ctc_oracle.greedy_decode(logits, ds.event_length)
+            bp = [ce.index2base(r) for r in rows if len(r)]
+            assert seg[1::2][:len(bp)] == bp and len(seg) == 2 * len(bp) + 1
+            cons = assembly.simple_assembly(bp, 390 / 400, kernal="glue")
+            assert fq[1] == ce.index2base(np.argmax(cons, axis=0))
     assert os.path.exists(os.path.join(out, "meta", "all.meta")) and os.path.isdir(os.path.join(out, "log"))
-    # same read, default preset beam (30): runs through the device beam search
+    # one read, default preset beam (30): runs through the device beam search
+    one = tmp_path / "one"
+    one.mkdir()
+    shutil.copy(os.path.join(ex, "read1.fast5"), str(one / "read1.fast5"))
     out2 = str(tmp_path / "out2")
-    entry.main(["call", "-i", str(inp), "-o", out2, "-m", model, "-p", "dna-pre", "-b", "100", "--synthetic-weights"])
+    entry.main(["call", "-i", str(one), "-o", out2, "-m", model, "-p", "dna-pre", "-b", "100", "--synthetic-weights"])
     fq2 = open(os.path.join(out2, "result", "read1.fastq")).read().split("\n")
     assert fq2[0] == "@read1" and len(fq2[1]) == len(fq2[3]) > 0
+
+
+def test_sharded_call_equals_single_process(tmp_path):
+    """BASELINE configs[3] path, scaled to the test box: synthetic 100k-sample reads as .signal files, `chiron call` once
+    as one process and once as two ranks under torch.distributed.run (both on GPU 0: CHIRON_SHARE_GPU self-test; per-read
+    partition, every rank packs its own batches, rank 0 gathers on the host).  merged.fastq and every result / segments
+    file must be byte-identical: population BN and a repack-stable engine make a window's output independent of the
+    batch it travels in."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import shard_run
+    rep = shard_run.run(str(tmp_path), n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100)
+    assert rep["identical"] and rep["files_compared"] == 18 and rep["consensus_bases"] > 0
+    merged = open(os.path.join(str(tmp_path), "out_2ranks", "merged.fastq")).read().split("\n")
+    assert [l for l in merged[0::4] if l] == ["@read%05d" % i for i in range(9)]
