@@ -10,6 +10,12 @@ in HBM: CNN -> 3x BiLSTM -> FC -> greedy CTC -> SparseTensor on device, decoded 
 the host, per-read regroup + glue overlap-consensus vote on the host.  Three batches are kept in
 flight (three engine slots / HIP streams; --slots).
 
+Timed region: --steps K steps take ~12 ms each, so K = 20 would be a quarter of a second -- too short for the
+clocks to settle or for a 1 Hz utilisation sampler to see the GPU busy.  The region therefore runs the K steps
+--rounds R times back to back (default 10: 200 steps, ~2.5 s), all inside ONE barrier + synchronize bracket;
+ms_per_step = time / (K * R), value = windows of all K * R steps / time, and the line reports steps = K, rounds = R,
+timed_steps = K * R.  Nothing is skipped or cached between rounds: every step is a full submit / collect.
+
 value = signal-normalised kbases/s = windows * jump / (4000 Hz / 450 b/s) / seconds / 1000
 (SURVEY.md 8d (i)); decoded consensus bases/s with the synthetic weights is reported in "extra".
 """
@@ -65,6 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rounds", type=int, default=10, help="the timed region is --steps steps repeated this many times (one bracket)")
     ap.add_argument("--slots", type=int, default=3, help="batches in flight (engine slots / HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
@@ -157,7 +164,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    timed_steps = args.steps * max(1, args.rounds)
+    for i in range(timed_steps):
         step(i, pending)
     drain(pending)
     eng.sync()
@@ -173,7 +181,7 @@ def main():
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         decoded_bases[0], consensus_bases[0] = int(agg[0].item()), int(agg[1].item())
 
-    windows = args.steps * BATCH * world
+    windows = timed_steps * BATCH * world
     kbases = windows * BASES_PER_WINDOW / 1000.0
     value = kbases / dt
 
@@ -198,10 +206,18 @@ def main():
         roofline = {"kernel": DOM_KERNEL, "bound": "mfma",
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate pass: %s)" % traffic_src,
+                    "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 of a separate rocprofv3 --pmc pass",
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
-                    "flops_per_launch": dom["flops"] / dom["launches"]}
+                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    # the north-star figure -- LSTM-GEMM FLOPs of all windows / whole-job time / fp32 MFMA peak
+                    "lstm_gemm_roofline_frac_whole_path": round(windows / dt * LSTM_GEMM_FLOP_PER_WINDOW / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4),
+                    "lstm_gemm_flop_per_window": LSTM_GEMM_FLOP_PER_WINDOW,
+                    # the kernel furthest below the roofline, same HIP-event pass: the recurrence (2*2*B*T*H*4H FLOP per launch)
+                    "lstm_recurrence": {"achieved": round(stats["lstm_recurrence"]["flops"] / (stats["lstm_recurrence"]["total_ms"] * 1e-3) / 1e12, 2),
+                                        "frac": round(stats["lstm_recurrence"]["flops"] / (stats["lstm_recurrence"]["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                        "avg_launch_ms": round(stats["lstm_recurrence"]["total_ms"] / stats["lstm_recurrence"]["launches"], 4)},
+                    "traffic_source": traffic_src}
         fam = [s for k, s in stats.items() if k.startswith("conv_") or k.startswith("lstm_proj")]
         gemm_family = {"launches_per_batch": sum(s["launches"] for s in fam) / 3.0,
                        "tflops": round(sum(s["flops"] for s in fam) / (sum(s["total_ms"] for s in fam) * 1e-3) / 1e12, 2),
@@ -212,7 +228,8 @@ def main():
         out = {
             "metric": "kilobases/sec basecalled (DNA_default seg_len=400 batch=1100)",
             "value": round(value, 2), "unit": "kbases/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "rounds": max(1, args.rounds), "timed_steps": timed_steps, "timed_region_s": round(dt, 3),
+            "warmup": args.warmup, "ms_per_step": round(dt / timed_steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DNA_default seg_len=400 jump=390 batch=1100 greedy, synthetic 4 kHz signal "
                                    "(BASELINE.json configs[1])", "segment_len": SEG_LEN, "jump": JUMP,
@@ -222,7 +239,7 @@ def main():
             "extra": {"windows_per_s": round(windows / dt, 1),
                       "decoded_bases_per_s": round(decoded_bases[0] / dt, 1),
                       "consensus_bases_per_s": round(consensus_bases[0] / dt, 1),
-                      "lstm_gemm_roofline_frac_whole_path": round(windows / dt * LSTM_GEMM_FLOP_PER_WINDOW / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                      "lstm_gemm_roofline_frac_whole_path": round(windows / dt * LSTM_GEMM_FLOP_PER_WINDOW / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4),
                       "model_tflops_whole_path": round(windows / dt * EXECUTED_FLOP_PER_WINDOW / 1e12, 2),
                       "model_tflops_reference_op_count": round(windows / dt * MODEL_FLOP_PER_WINDOW / 1e12, 2),
                       "gemm_family": gemm_family, "kernels": per_kernel}}
@@ -306,18 +323,38 @@ def split_config(spec, weights, x_dev, s_dev, ref32, device_id):
                                      "greedy_decode_identical": bool(same), "windows": BATCH}}
 
 
+def kernel_sources_digest():
+    """SHA-256 over the HIP sources: a PMC record is only valid for the kernels it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "chiron_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the most recent committed PMC pass under profiles/
-    (tools/pmc_pass.sh + tools/pmc_to_json.py; rocprofv3 cannot run inside the timed process)."""
+    """HBM bytes per launch of `kernel` from the most recent committed PMC pass under profiles/ (tools/pmc_pass.sh +
+    tools/pmc_to_json.py; rocprofv3 cannot wrap the timed process from inside).  The record carries the digest of the
+    kernel sources it was measured on; when the sources have changed since, the number is withheld (traffic = null)
+    and the source string says so -- a stale constant is never reported as this run's traffic."""
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not cands:
-        return None, "none"
+        return None, "none: no profiles/r*_pmc.json"
+    name = "profiles/" + os.path.basename(cands[-1])
     try:
-        rec = json.load(open(cands[-1])).get(kernel, {})
-        return rec.get("hbm_bytes"), os.path.basename(cands[-1])
+        doc = json.load(open(cands[-1]))
     except (OSError, ValueError):
-        return None, "unreadable"
+        return None, "unreadable: " + name
+    have, want = doc.get("_kernel_sources_sha256_16"), kernel_sources_digest()
+    if have != want:
+        sys.stderr.write("bench.py: %s was collected on kernel sources %s, the tree holds %s: roofline.traffic withheld; "
+                         "re-run tools/pmc_pass.sh + tools/pmc_to_json.py\n" % (name, have, want))
+        return None, "STALE: %s was collected on kernel sources %s, this tree is %s" % (name, have, want)
+    return doc.get(kernel, {}).get("hbm_bytes"), "static %s @ kernel sources %s (separate --pmc pass, not this run)" % (name, want)
 
 
 def cpu_baseline(spec, weights, xb, lb, ratio, n_windows):

@@ -29,8 +29,11 @@ def main():
             f = family(r["Kernel_Name"])
             if f:
                 acc[f][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out = {"_note": "mean per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction)",
-           "_command": "tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 3 --warmup 1 --slots 1 --no-cpu-baseline --no-f16"}
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    import bench
+    out = {"_kernel_sources_sha256_16": bench.kernel_sources_digest(),
+           "_note": "mean per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction)",
+           "_command": "tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 3 --rounds 1 --warmup 1 --slots 1 --no-cpu-baseline --no-f16"}
     for f, c in acc.items():
         m = {k: sum(v) / len(v) for k, v in c.items()}
         rec = {"launches_sampled": len(c.get("FETCH_SIZE", c.get("SQ_WAVE_CYCLES", [])))}
