@@ -9,7 +9,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libchiron_amd.so")
+# CHIRON_AMD_LIB: another build of the same library (A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get("CHIRON_AMD_LIB") or os.path.join(_HERE, "csrc", "libchiron_amd.so")
 
 MAX_BLOCKS = 8
 CLASSES = 5

@@ -150,6 +150,7 @@ struct LstmPlan {
   ConvGemmPlan proj[2];  // STACK / layer 0: proj[0] covers both directions; MULTI l>0: one per dir
   int nproj = 1;
   float* wfrag = nullptr;
+  float* wlight = nullptr;  // K-split fragment of units 96..99 for the paired recurrence (fp32, H = 100)
 };
 
 struct ProfEvent {
@@ -210,7 +211,7 @@ struct chiron_engine {
   chiron_engine_opts opts;
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
-  int lstm_rows = 4;   // batch rows per recurrence workgroup (4, 8 or 16)
+  bool lstm_paired = false;  // fp32 recurrence: 14-wave workgroups for the part of a batch that fits one resident round
   bool bn_batch = false;  // desc.bn_mode == CHIRON_BN_BATCH
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
   bool split = false;  // opts.dtype == CHIRON_F32_SPLIT: fp32 values as hi/lo half pairs on the f16 matrix cores (GEMMs only)
@@ -563,6 +564,18 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
     } else if ((st = dev_upload(e, &lp.wfrag, wf))) {
       return st;
     }
+    if (!e->f16) {
+      // light-wave fragment of lstm_pair_kernel: [dir][m = 4q + a][lane = kg*16 + gate*4 + j] = W_hh[16q + 4kg + a][gate*H + 96 + j]
+      std::vector<float> wl((size_t)2 * 28 * 64, 0.f);
+      for (int dir = 0; dir < 2; ++dir)
+        for (int m = 0; m < 28; ++m)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int q = m >> 2, a = m & 3, kg = lane >> 4, g = (lane >> 2) & 3, j = lane & 3;
+            const int k = 16 * q + 4 * kg + a;
+            if (k < H) wl[((size_t)dir * 28 + m) * 64 + lane] = kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + 96 + j];
+          }
+      if ((st = dev_upload(e, &lp.wlight, wl))) return st;
+    }
     e->lstm.push_back(lp);
   }
   // ---- FC head (raw)
@@ -724,11 +737,10 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   // starts on a block boundary (fw at 0, bw at roundup(H, 32))
   e->lasth_ld = !e->split ? 2 * desc->hidden
                 : desc->rnn_kind == CHIRON_RNN_MULTI ? 2 * roundup(desc->hidden, 32) : roundup(2 * desc->hidden, 32);
-  {
-    const char* ev = getenv("CHIRON_LSTM_ROWS");  // tuning knob; results do not depend on it
-    const int r = ev ? atoi(ev) : 4;
-    e->lstm_rows = (r == 8 || r == 16) ? r : 4;
-  }
+  // Tuning knob, off by default; results do not depend on it (same arithmetic per row).  Paired workgroups are 14 %
+  // faster per resident round, but they fill their CU: with several batches in flight the 7-wave form, which shares a CU
+  // with another slot's GEMM workgroups, gives the higher throughput (3905 vs 4004 kbases/s on one box).
+  e->lstm_paired = getenv("CHIRON_LSTM_PAIR") != nullptr;
   st = build_plans(e, weights);
   if (st == CHIRON_OK) {
     e->slots.resize(e->opts.n_slots);
@@ -1065,6 +1077,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     LstmParams r;
     r.z = s->z;
     r.wfrag = lp.wfrag;
+    r.wlight = lp.wlight;
     r.seq_len = s->seq;
     r.out = e->split ? s->lasth_f32 : outbuf;
     r.T = T;
@@ -1072,7 +1085,8 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.BP = BP;
     r.H = H;
     r.ndir = 2;
-    r.rows_per_wg = e->lstm_rows;
+    r.paired = e->lstm_paired ? 1 : 0;
+    r.group0 = 0;
     r.f16 = e->f16 ? 1 : 0;
     {
       Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H, 4.0 * B * T * 2.0 * (zc + H));

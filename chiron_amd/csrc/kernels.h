@@ -79,17 +79,21 @@ bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel 
 // LSTM recurrence (lstm.hip): one workgroup = 4*NG batch rows x one direction x all T steps.
 // ---------------------------------------------------------------------------------------------
 constexpr int LSTM_K = 100;      // hidden size the kernel is built for (rnn.py:23 hidden_num=100)
-constexpr int LSTM_NW = 7;       // waves per workgroup; wave w owns hidden units [16w, 16w+16)
+constexpr int LSTM_NW = 7;       // waves per 4-row group: six own hidden units [16w, 16w+16), the seventh units 96..99 (fp32) / [96, 112) (f16)
 
 struct LstmParams {
   const float* z;        // [T][BP/4][ndir][4*H][4 rows]  x-projection + bias, column = gate*H + unit; direction 1 is
                          //   indexed by STEP (frame seq_len-1-s), direction 0 by frame
   const float* wfrag;    // [ndir][LSTM_NW][LSTM_K][64 lanes] recurrent weights, fragment order
+  const float* wlight;   // [ndir][28][64 lanes] units 96..99 in the K-split order of the light wave (fp32 kernel):
+                         //   entry m = 4q + a, lane = kg*16 + gate*4 + j  ->  W_hh[k = 16q + 4kg + a][gate*H + 96 + j]
   const int32_t* seq_len;  // [BP] (0 for padded rows)
   float* out;            // lasth [T][BP][ndir*H] time major
   int T, B, BP, H;
   int ndir;              // 2
-  int rows_per_wg;       // 4, 8 or 16
+  int paired;            // fp32: 1 = 14-wave workgroups (two groups per CU) for the part of the batch that fits one resident round
+  int group0;            // first 4-row group this launch covers (blockIdx 0); launch_lstm splits a batch into a paired part
+                         //   and a remainder
   int f16;               // 1: wfrag holds halves in 4x4x4 fragment order, out (lasth) is written as halves; z stays fp32
 };
 void launch_lstm(const LstmParams& p, hipStream_t stream);

@@ -2,13 +2,13 @@
 // sequence_length (chiron/rnn.py:49-65 / :140-145; op composition recorded in the shipped .meta
 // graphs) as ONE persistent launch per layer.
 //
-//   workgroup = 4*NG batch rows x 1 direction, resident for all T steps (rows never interact, so no
-//   grid-wide sync exists).  7 waves; wave w owns hidden units [16w, 16w+16) for all four gates = 64
-//   matrix columns = exactly the N extent of ONE v_mfma_f32_4x4x1_16B_f32 (16 blocks of a 4x4 outer
-//   product: M = 4 batch rows, N = 64 columns, K = 1).  Its slice of W_hh lives in VGPRs for the whole
-//   sequence (100 registers per lane; W_hh = 160 KB fp32 = the entire LDS, spread over 7 register files).
-//   The 4-row MFMA shape is what lets B = 1100 fill the chip: 16-row tiles give 138 workgroups for 256
-//   CUs, 4-row groups give 550 half-CU workgroups; the instruction runs at the same 64 FLOP/clk/SIMD.
+//   workgroup = 4 or 8 batch rows (one or two 4-row groups) x 1 direction, resident for all T steps (rows never
+//   interact, so no grid-wide sync exists).  7 waves per group; heavy wave w owns hidden units [16w, 16w+16) for all
+//   four gates = 64 matrix columns = exactly the N extent of ONE v_mfma_f32_4x4x1_16B_f32 (16 blocks of a 4x4 outer
+//   product: M = 4 batch rows, N = 64 columns, K = 1).  Its slice of W_hh lives in VGPRs for the whole sequence
+//   (100 registers per lane; W_hh = 160 KB fp32 = the entire LDS, spread over the waves' register files).
+//   The 4-row MFMA shape is what lets B = 1100 fill the chip: 16-row tiles give 138 workgroups for 256 CUs, 4-row
+//   groups give 550 group-directions; the instruction runs at the same 64 FLOP/clk/SIMD.
 //   (v_mfma_f32_* shares the fp32 VALU datapath -- tools/ubench/barrier_mfma.hip -- so the gate math can
 //   not hide behind it; what counts is total issue time, and this layout needs ONE cell per lane.)
 //
@@ -21,6 +21,8 @@
 //   t = seq_len-1-s per row (tf.reverse_sequence folded into index arithmetic, no copy): its z is stored by step
 //   by the projection GEMM, its output frame index is per-lane arithmetic.
 #include "kernels.h"
+
+#include <algorithm>
 
 // Every multiply-add below is written out (fmaf or separate ops) so that a row's result does not depend on
 // which register slot / row position it occupies: batches can be re-packed without changing a bit.
@@ -78,130 +80,167 @@ __device__ __forceinline__ f32x4 gate_transpose(f32x4 v) {
   return (f32x4){__uint_as_float(a), __uint_as_float(b), __uint_as_float(c), __uint_as_float(d)};
 }
 
-template <int NG>
-__global__ __launch_bounds__(64 * LSTM_NW, NG == 1 ? 4 : 2) void lstm_kernel(const LstmParams p) {
-  __shared__ __attribute__((aligned(16))) float hbuf[2 * NG * HG];
+// ---------------------------------------------------------------------------------------------------------
+// The fp32 recurrence.  One workgroup = NGRP (1 or 2) 4-row groups of one direction, 7 waves per group:
+//   SIX heavy waves: wave w owns hidden units [16w, 16w + 16) for all four gates = 64 matrix columns = the N extent of
+//     one v_mfma_f32_4x4x1_16B_f32; 100 MFMAs per step, its slice of W_hh (100 registers per lane) resident for the
+//     whole sequence;
+//   ONE light wave for units 96..99: their 16 columns (4 gates x 4 units) occupy four MFMA blocks, and cbsz = 2
+//     broadcasts a different A block to each group of four blocks, so the four block groups take four different k
+//     (tools/ubench/mfma4x4_bcast2.hip): 28 MFMAs cover K = 100 instead of 100 MFMAs with 48 of 64 columns multiplying
+//     zeros.  The four partial sums of a column are joined through 1 KB of LDS inside the wave (no extra barrier) in a
+//     fixed order, then the same register transpose and cell update as the heavy waves.
+// NGRP = 2 ("paired", 14 waves = a whole CU): fp32 MFMA and VALU share a SIMD's pipe, so what sets the step time is the
+// fullest SIMD.  Two 7-wave workgroups put 4, 4, 3, 3 waves on the four SIMDs wherever the dispatcher starts them; one
+// 14-wave workgroup's waves go to the SIMDs in cyclic order, so with the two light waves LAST the loads are
+// 3 heavy + light, 3 heavy + light, 3 heavy, 3 heavy: 0.69 ms instead of 0.80 ms per resident round at T = 400.
+// A paired workgroup fills its CU; launch_lstm uses it for as many groups as fit one round (256 CUs x 8 rows = 1024
+// rows) and NGRP = 1 for the rest.  Both forms do the same arithmetic for a row, so a row's result does not depend on
+// where in the batch it sits.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int REC_HEAVY = 6;                   // heavy waves per group: wave w owns units [16w, 16w + 16)
+constexpr int LIGHT_MF = 28;                   // MFMAs of a light wave per step: q = 0..6 times abid = 0..3
+static_assert(REC_HEAVY + 1 == LSTM_NW, "7 waves per group");
+
+template <int NGRP>
+__global__ __launch_bounds__(64 * LSTM_NW * NGRP, 4) void lstm_kernel(const LstmParams p) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2 * NGRP * HG];    // [buffer][group][HG]
+  __shared__ __attribute__((aligned(16))) float part[NGRP * 256];       // light waves: [group][lane][4 rows] K-split partial sums
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dir = blockIdx.x % p.ndir;
-  const int g0 = (blockIdx.x / p.ndir) * NG;  // first 4-row group of this workgroup
+  const int gbase = p.group0 + (blockIdx.x / p.ndir) * NGRP;            // first 4-row group of this workgroup
+  const bool light = wave >= NGRP * REC_HEAVY;
+  const int grp = light ? wave - NGRP * REC_HEAVY : wave / REC_HEAVY;   // group inside the workgroup
+  const int hq = light ? 6 : wave % REC_HEAVY;                           // k-group (tile q of the h buffer) this wave's cells write
+  const int g0 = gbase + grp;                                            // this wave's 4-row group
 
-  // ---- this wave's 64 columns of the recurrent weights (fragment order prepared on the host)
+  // ---- recurrent weights of this wave: 100 registers (heavy: its 64 columns for every k) or 28 (light: K-split)
   float w[LSTM_K];
-  {
-    const float* wf = p.wfrag + ((long)dir * LSTM_NW + wave) * LSTM_K * 64 + lane;
+  if (!light) {
+    const float* wf = p.wfrag + ((long)dir * LSTM_NW + hq) * LSTM_K * 64 + lane;
 #pragma unroll
     for (int k = 0; k < LSTM_K; ++k) w[k] = wf[k * 64];
+  } else {
+    const float* wl = p.wlight + (long)dir * LIGHT_MF * 64 + lane;
+#pragma unroll
+    for (int m = 0; m < LIGHT_MF; ++m) w[m] = wl[m * 64];
   }
-  for (int i = tid; i < 2 * NG * HG; i += 64 * LSTM_NW) hbuf[i] = 0.f;
+  for (int i = tid; i < 2 * NGRP * HG; i += 64 * LSTM_NW * NGRP) hbuf[i] = 0.f;
 
-  const int unit = wave * 16 + (lane & 15);
-  const int row = lane >> 4;  // after the transpose: this lane's batch row within the group
-  const bool live = unit < p.H;
-  int lenr[NG];               // length of this lane's row
-  int maxlen = 0;             // longest row of the workgroup (wave-uniform)
+  // the cell this lane owns after the transpose: heavy (row = lane >> 4, unit = 16 hq + lane & 15); light: lanes hold
+  // the 16 cells (row = (lane & 15) >> 2, unit = 96 + (lane & 3)) four times over, lanes 0..15 store
+  const int row = light ? (lane & 15) >> 2 : lane >> 4;
+  const int unit = light ? 96 + (lane & 3) : hq * 16 + (lane & 15);
+  const int lenr = min(p.seq_len[g0 * 4 + row], p.T);
+  int maxlen = 0;   // longest row of the WORKGROUP: every wave runs the same number of steps (one barrier each)
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    lenr[g] = min(p.seq_len[(g0 + g) * 4 + row], p.T);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) maxlen = max(maxlen, min(p.seq_len[(g0 + g) * 4 + r], p.T));
-  }
+  for (int r = 0; r < 4 * NGRP; ++r) maxlen = max(maxlen, min(p.seq_len[gbase * 4 + r], p.T));
   __syncthreads();
 
-  // all offsets are 32-bit element indices (z: < 2^29 floats at B = 1100, T = 400): scalar base + one VGPR
   const unsigned outw = p.ndir * p.H;
-  // z column of this lane before the transpose (lane = gate*16 + unit): gate*H + unit, the plain TF kernel order;
-  // lanes of units past H read a valid column (their cells are never stored)
   const unsigned zcols = 4 * p.H;
-  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;  // floats between consecutive steps
-  const unsigned zlane = ((g0 * p.ndir + dir) * zcols + (lane >> 4) * p.H + min(wave * 16 + (lane & 15), p.H - 1)) * 4;
-  const unsigned zgrp = p.ndir * zcols * 4;                 // floats between consecutive row groups
-  const unsigned ostep = p.BP * outw;                            // floats between consecutive frames of the output
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;   // floats between consecutive steps
+  // heavy: lane = gate*16 + unit reads its column's 4 rows (16 bytes); light: lane = gate*16 + row*4 + j reads one float
+  const unsigned zlane_b = light ? (((g0 * p.ndir + dir) * zcols + (lane >> 4) * p.H + 96 + (lane & 3)) * 4 + ((lane >> 2) & 3)) * 4
+                                 : ((g0 * p.ndir + dir) * zcols + (lane >> 4) * p.H + hq * 16 + (lane & 15)) * 16;
+  const unsigned ostep = p.BP * outw;
   const unsigned olane = (g0 * 4 + row) * outw + dir * p.H + unit;
-  const int hw = wave * 64 + (lane & 15) * 4 + row;              // where this lane's cell writes h: q = wave, blk = unit & 15
+  const int hw = light ? 6 * 64 + (lane & 3) * 4 + row : hq * 64 + (lane & 15) * 4 + row;   // [q][blk][row]
 
-  float c[NG], hprev[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) c[g] = hprev[g] = 0.f;
-
-  // z of step s: ONE 16-byte load per lane and group.  The projection GEMM stores the backward direction by step
-  // (frame seq_len-1-s of each row, gemm.hip ZGroup), so neither direction needs per-row addressing here.
-  // hipcc sinks an ordinary load down to its first use, where every step would pay a full HBM round trip.  So the
-  // load is issued by hand at the TOP of the step and waited for after the MFMAs: with 3-4 waves sharing the SIMD
-  // that is 2-3 us later, enough even for an HBM miss (an extra 4-byte "touch" two steps ahead cost more issue time
-  // than it saved).  Registers are the limit here -- 128 per lane with two workgroups per CU, 100 of them hold
-  // W_hh -- which rules out a double-buffered 16-byte prefetch.
-  const unsigned zlane_b = zlane * 4;  // byte offset of this lane inside a step's z slab (scalar base + VGPR offset)
+  float c = 0.f, hprev = 0.f;
   int cur = 0;
-  for (int s = 0; s < maxlen; ++s) {
-    f32x4 z[NG];
-    {
-      const float* zs = p.z + (size_t)s * zstep;  // wave-uniform
+  // Two loops, one per role, with the same trip count and one s_barrier per step each: the hardware barrier counts
+  // arrivals, so heavy and light waves meet at it from different program points.  (One loop with a role branch inside
+  // makes the register allocator keep both roles' values live and spills.)
+  if (!light) {
+    for (int s = 0; s < maxlen; ++s) {
+      const float* zs = p.z + (size_t)s * zstep;   // wave-uniform
+      f32x4 z4;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z4) : "v"(zlane_b), "s"(zs) : "memory");
+      const float* hb = hbuf + (cur * NGRP + grp) * HG + lane;
+      float hv[7];
 #pragma unroll
-      for (int g = 0; g < NG; ++g)
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z[g]) : "v"(zlane_b), "s"(zs + g * zgrp) : "memory");
-    }
-    // ---- acc = h_{s-1} . W_hh : A = h[row][k] broadcast from block k&15, B = this lane's column of W_hh.
-    //      One accumulator per group: the 12-cycle dependent-issue latency of the chain is covered by the other
-    //      waves of the SIMD (3-4 are resident), a second accumulator would cost 4 registers that do not exist.
-    f32x4 acc[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* hb = hbuf + cur * (NG * HG) + lane;
-    float hv[NG][7];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int q = 0; q < 7; ++q) hv[g][q] = hb[g * HG + q * 64];
+      for (int q = 0; q < 7; ++q) hv[q] = hb[q * 64];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #define CHIRON_MF(B)                                                                                       \
-  if (16 * q + (B) < LSTM_K)                                                                                \
-    acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq, w[(16 * q + (B)) % LSTM_K], acc[g], 4, B, 0);
+  if (16 * q + (B) < LSTM_K) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(hv[q], w[(16 * q + (B)) % LSTM_K], acc, 4, B, 0);
 #pragma unroll
-    for (int q = 0; q < (LSTM_K + 15) / 16; ++q) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const float hq = hv[g][q];
+      for (int q = 0; q < 7; ++q) {
         CHIRON_MF(0) CHIRON_MF(1) CHIRON_MF(2) CHIRON_MF(3) CHIRON_MF(4) CHIRON_MF(5) CHIRON_MF(6) CHIRON_MF(7)
         CHIRON_MF(8) CHIRON_MF(9) CHIRON_MF(10) CHIRON_MF(11) CHIRON_MF(12) CHIRON_MF(13) CHIRON_MF(14) CHIRON_MF(15)
       }
-    }
 #undef CHIRON_MF
-#pragma unroll
-    for (int g = 0; g < NG; ++g)  // tied to the accumulators as well: the scheduler must not move the wait ahead of the MFMAs
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[g]), "+v"(acc[g]));
-    // ---- gates: transpose (lane = gate*16+unit, reg = row) -> (lane = row*16+unit, reg = gate)
-    float* hn = hbuf + (cur ^ 1) * (NG * HG);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const f32x4 q = gate_transpose(acc[g] + z[g]);  // i, j, f, o of (row, unit)
-      // rows past their length carry (c, h) and emit zeros (dynamic_rnn); whatever their z slot held is discarded
-      const bool act = s < lenr[g];
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(z4), "+v"(acc));   // tied to the accumulators: not ahead of the MFMAs
+      const f32x4 gates = gate_transpose(acc + z4);                // i, j, f, o of (row, unit)
+      const bool act = s < lenr;
       float hnew;
-      const float cn = lstm_cell(q, c[g], &hnew);
-      c[g] = act ? cn : c[g];
-      hprev[g] = act ? hnew : hprev[g];
-      if (live) {
-        hn[g * HG + hw] = hprev[g];
-        const unsigned to = (dir == 0 || !act) ? s : lenr[g] - 1 - s;  // the backward direction walks its frames from the end
-        // 32-bit BYTE offset from the scalar base: the store takes the saddr + voffset form, no 64-bit address math
-        const unsigned ob = (to * ostep + g * 4 * outw + olane) * 4u;
+      const float cn = lstm_cell(gates, c, &hnew);
+      c = act ? cn : c;
+      hprev = act ? hnew : hprev;
+      hbuf[((cur ^ 1) * NGRP + grp) * HG + hw] = hprev;
+      const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+      const unsigned ob = (to * ostep + olane) * 4u;
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + ob) = act ? hnew : 0.f;
+      cur ^= 1;
+      __syncthreads();
+    }
+  } else {
+    float* const mypart = part + grp * 256;
+    for (int s = 0; s < maxlen; ++s) {
+      const float* zs = p.z + (size_t)s * zstep;
+      float z1;
+      asm volatile("global_load_dword %0, %1, %2" : "=v"(z1) : "v"(zlane_b), "s"(zs) : "memory");
+      const float* hb = hbuf + (cur * NGRP + grp) * HG + lane;
+      float hv[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) hv[q] = hb[q * 64];
+      // block group kg = lane >> 4 takes k = 16 q + 4 kg + abid: D[lane = kg*16 + gate*4 + j][reg = row] = partial sum
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(hv[q], w[q * 4 + 0], acc, 2, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(hv[q], w[q * 4 + 1], acc, 2, 1, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(hv[q], w[q * 4 + 2], acc, 2, 2, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(hv[q], w[q * 4 + 3], acc, 2, 3, 0);
+      }
+      // join the four k-subsets inside the wave: lane (gate, row, j) adds partial[kg][gate][j][row], kg = 0..3 in order
+      *reinterpret_cast<f32x4*>(mypart + lane * 4) = acc;
+      __builtin_amdgcn_wave_barrier();
+      const float* src = mypart + (((lane >> 4) * 4 + (lane & 3)) * 4 + ((lane >> 2) & 3));
+      float sum = src[0];
+      sum += src[64];
+      sum += src[128];
+      sum += src[192];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(z1), "+v"(sum));
+      const float v = sum + z1;
+      const f32x4 gates = gate_transpose((f32x4){v, v, v, v});   // every lane (., r*4 + j): i, j, f, o of cell (r, 96 + j)
+      const bool act = s < lenr;
+      float hnew;
+      const float cn = lstm_cell(gates, c, &hnew);
+      c = act ? cn : c;
+      hprev = act ? hnew : hprev;
+      if (lane < 16) {
+        hbuf[((cur ^ 1) * NGRP + grp) * HG + hw] = hprev;
+        const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+        const unsigned ob = (to * ostep + olane) * 4u;
         *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + ob) = act ? hnew : 0.f;
       }
+      cur ^= 1;
+      __syncthreads();
     }
-    cur ^= 1;
-    __syncthreads();
   }
 
-  // ---- frames past the longest row of this workgroup read back as zeros (dynamic_rnn semantics)
-  for (int s = maxlen; s < p.T; ++s) {
-    for (int i = tid; i < NG * 4 * p.H; i += 64 * LSTM_NW) {
+  // ---- frames past the longest row of the workgroup read back as zeros (dynamic_rnn semantics)
+  for (int s = maxlen; s < p.T; ++s)
+    for (int i = tid; i < 4 * NGRP * p.H; i += 64 * LSTM_NW * NGRP) {
       const int r = i / p.H;
       const int u = i - r * p.H;
-      p.out[((long)s * p.BP + g0 * 4 + r) * outw + dir * p.H + u] = 0.f;
+      p.out[((long)s * p.BP + gbase * 4 + r) * outw + dir * p.H + u] = 0.f;
     }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -221,7 +260,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dir = blockIdx.x % p.ndir;
-  const int g0 = blockIdx.x / p.ndir;  // 4-row group of this workgroup
+  const int g0 = p.group0 + blockIdx.x / p.ndir;  // 4-row group of this workgroup
 
   f16x4 w[LSTM_KSTEPS16];
   {
@@ -440,19 +479,28 @@ void launch_split_convert(const float* src, void* dst, long rows, int cols, int 
 }
 
 
-void launch_lstm(const LstmParams& p, hipStream_t stream) {
+void launch_lstm(const LstmParams& p0, hipStream_t stream) {
   // hidden = 100 is the only size the reference's shipped models use (rnn.py:23 hidden_num=100)
+  LstmParams p = p0;
+  p.group0 = 0;
   const int groups = p.BP / 4;
-  const int ng = p.rows_per_wg / 4;
-  const dim3 block(64 * LSTM_NW);
-  if (p.f16)
-    hipLaunchKernelGGL(lstm16_kernel, dim3(groups * p.ndir), block, 0, stream, p);
-  else if (ng == 1)
-    hipLaunchKernelGGL(lstm_kernel<1>, dim3(groups * p.ndir), block, 0, stream, p);
-  else if (ng == 2)
-    hipLaunchKernelGGL(lstm_kernel<2>, dim3(groups / 2 * p.ndir), block, 0, stream, p);
-  else
-    hipLaunchKernelGGL(lstm_kernel<4>, dim3(groups / 4 * p.ndir), block, 0, stream, p);
+  if (p.f16) {
+    hipLaunchKernelGGL(lstm16_kernel, dim3(groups * p.ndir), dim3(64 * LSTM_NW), 0, stream, p);
+    return;
+  }
+  // Paired workgroups (one per CU) for as many groups as fit ONE resident round, 7-wave workgroups for the rest: a
+  // paired workgroup fills its CU, so a second round of them would cost a whole round however few there are.
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int pairs = p.paired ? std::min(groups / 2, n_cu / p.ndir) : 0;
+  if (pairs > 0) hipLaunchKernelGGL(lstm_kernel<2>, dim3(pairs * p.ndir), dim3(64 * LSTM_NW * 2), 0, stream, p);
+  p.group0 = 2 * pairs;
+  if (groups > p.group0) hipLaunchKernelGGL(lstm_kernel<1>, dim3((groups - p.group0) * p.ndir), dim3(64 * LSTM_NW), 0, stream, p);
 }
 
 }  // namespace chiron

@@ -342,6 +342,33 @@ def test_pipeline_end_to_end_on_example_signal(dna, tmp_path):
     assert open(os.path.join(F.output, "result", "tiny.fastq")).read().startswith("@tiny\n")
 
 
+def test_paired_recurrence_workgroups_give_identical_bits(dna, monkeypatch):
+    """lstm.hip lstm_kernel<2> (CHIRON_LSTM_PAIR=1: two 4-row groups per workgroup, 14 waves, for the rows that fit one
+    resident round) and lstm_kernel<1> do the same arithmetic for a row -- heavy waves 100 MFMAs in k order, the light
+    wave its K-split sum in a fixed order -- so logits are bit-identical whichever form a row meets, ragged rows and
+    zero-length rows included, and equal to the oracle within the fp32 bound."""
+    from oracle import nn_oracle
+    spec, w = dna
+    L, B = 400, 70
+    x, ln = _windows(390 * (B - 1) + 123, L, 390, seed=41)
+    ln = ln.copy()
+    ln[[2, 9, 33]] = [0, 1, 250]
+    out = []
+    for paired in (False, True):
+        if paired:
+            monkeypatch.setenv("CHIRON_LSTM_PAIR", "1")
+        else:
+            monkeypatch.delenv("CHIRON_LSTM_PAIR", raising=False)
+        with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
+            sl = ca.seq_len_for_engine(ln, eng.ratio)
+            out.append(eng.infer(x, sl, want_logits=True).logits.copy())
+    monkeypatch.delenv("CHIRON_LSTM_PAIR", raising=False)
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+    rows = [0, 2, 9, 33, 69]
+    ref, _ = nn_oracle.inference(x[rows], sl[rows], spec.to_dict(), w, dtype=np.float64)
+    assert np.abs(out[0][rows] - ref).max() < TOL
+
+
 def _beam_rows(res, B):
     got = [[] for _ in range(B)]
     for (r, _), v in zip(res.decoded.indices, res.decoded.values):
