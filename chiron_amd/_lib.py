@@ -80,6 +80,8 @@ SYMBOLS = [
                                   C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     ("chiron_overlap_displacement", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
                                               C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    ("chiron_consensus_device", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_int64, C.POINTER(C.c_int64)]),
     ("chiron_crc32c", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("chiron_last_error", C.c_char_p, []),
     ("chiron_abi_version", C.c_int32, []),

@@ -110,3 +110,22 @@ def simple_assembly_qs(bpreads, qs_list, jump_step_ratio, error_rate=0.2, kernal
     bases, off = encode(bpreads)
     seg_qs = np.asarray(qs_list, dtype=np.float64).reshape(len(bpreads), -1)[:, 0] if len(bpreads) else np.zeros(0)
     return assemble_native(bases, off, seg_qs, kernal, error_rate, jump_step_ratio)
+
+
+def consensus_device(bpreads, qs_list, kernal, device_id=0):
+    """chiron_consensus_device: glue / stick displacements, vote, argmax and quality string of ONE read on the GPU
+    -> (consensus 'ACGT' string, Phred+33 string or None).  Equal to simple_assembly_qs + argmax + eval.qs."""
+    kid = _kernal_id(kernal)
+    if kernal == "simple":
+        raise ValueError("the device vote covers the glue and stick kernels; simple displacements are host code")
+    bases, off = encode(bpreads)
+    qs = None if qs_list is None else np.ascontiguousarray(np.asarray(qs_list, dtype=np.float64).reshape(len(bpreads), -1)[:, 0])
+    cap = int(bases.shape[0]) + 1
+    cons = np.empty(cap, dtype=np.uint8)
+    qual = np.empty(cap, dtype=np.uint8) if qs is not None else None
+    n = C.c_int64()
+    _lib.check(_lib.load().chiron_consensus_device(int(device_id), bases.ctypes.data, off.ctypes.data, len(bpreads),
+                                                   None if qs is None else qs.ctypes.data, kid, cons.ctypes.data,
+                                                   None if qual is None else qual.ctypes.data, cap, C.byref(n)))
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[cons[:n.value]].tobytes().decode("ascii")
+    return seq, (None if qual is None else qual[:n.value].tobytes().decode("latin1"))

@@ -25,6 +25,7 @@ from .engine import Engine, SparseTensor, seq_len_for_engine
 from .unix_time import unix_time
 
 BASES = "ACGT"
+DEVICE_VOTE_MIN_SEGMENTS = 8192      # reads with at least this many decoded windows take the device-side consensus vote
 
 
 def _rows_of(sparse):
@@ -294,12 +295,17 @@ def finish_read(name, reads, qs_list, FLAGS, t_start, reading_time):
     js_ratio = FLAGS.jump / FLAGS.segment_len
     kernal = get_assembler_kernal(FLAGS.jump, FLAGS.segment_len)
     qs_string = None
-    if FLAGS.extension == "fastq":
+    if kernal != "simple" and len(bpreads) >= getattr(FLAGS, "device_vote_min_segments", DEVICE_VOTE_MIN_SEGMENTS):
+        # very long reads: displacements, vote, argmax and quality string in one pass on the GPU
+        c_bpread, qs_string = assembly.consensus_device(bpreads, qs_list if FLAGS.extension == "fastq" else None, kernal,
+                                                        getattr(FLAGS, "device", 0))
+    elif FLAGS.extension == "fastq":
         consensus, qs_consensus = assembly.simple_assembly_qs(bpreads, qs_list, js_ratio, kernal=kernal)
         qs_string = qs(consensus, qs_consensus)
+        c_bpread = index2base(np.argmax(consensus, axis=0))
     else:
         consensus = assembly.simple_assembly(bpreads, js_ratio, kernal=kernal)
-    c_bpread = index2base(np.argmax(consensus, axis=0))
+        c_bpread = index2base(np.argmax(consensus, axis=0))
     assembly_time = time.time() - t_start
     write_output(bpreads, c_bpread, [t_start, reading_time, basecall_time, assembly_time], file_pre,
                  concise=FLAGS.concise, suffix=FLAGS.extension, q_score=qs_string, global_setting=FLAGS)

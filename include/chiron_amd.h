@@ -233,6 +233,17 @@ chiron_status chiron_overlap_displacement(const uint8_t* cur, int64_t n, const u
                                           int32_t kernal, double error_rate, double jump_step_ratio, int64_t* disp,
                                           double* log_px);
 
+/* The same consensus on the device, for one read (very long reads): glue / stick displacements of every
+ * consecutive segment pair, running start columns, the vote, and per consensus column the winning base
+ * (np.argmax(consensus, axis=0), chiron_eval.py:457: first maximum) and, when seg_qs is given, its Phred+33 character
+ * (qs(), chiron_eval.py:152-174) -- i.e. chiron_assemble + argmax + qs without the [4][len] matrices ever leaving the
+ * GPU.  Host pointers in and out; the call owns a stream and its device buffers (thread-safe, independent of any
+ * engine).  consensus [cap] receives 0..3, quality [cap] (may be NULL) the characters; *out_len the length;
+ * CHIRON_ERR_OVERFLOW if cap is too small (then *out_len = needed).  kernal: CHIRON_KERNAL_GLUE or _STICK.        */
+chiron_status chiron_consensus_device(int32_t device_id, const uint8_t* bases, const int64_t* seg_off, int64_t n_seg,
+                                      const double* seg_qs, int32_t kernal, uint8_t* consensus, uint8_t* quality,
+                                      int64_t cap, int64_t* out_len);
+
 /* Host-side reader of the reference's raw-signal text format: chiron_input.py:527-539 read_signal() --
  * `f.read().split()` converted to float32 -- whitespace/newline separated numbers.  Each token is parsed as a
  * C double (like Python's float()) and then narrowed to float32, so the values equal numpy's conversion.

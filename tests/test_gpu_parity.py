@@ -773,3 +773,62 @@ def test_sharded_call_equals_single_process(tmp_path):
     assert rep["identical"] and rep["files_compared"] == 18 and rep["consensus_bases"] > 0
     merged = open(os.path.join(str(tmp_path), "out_2ranks", "merged.fastq")).read().split("\n")
     assert [l for l in merged[0::4] if l] == ["@read%05d" % i for i in range(9)]
+
+
+def test_device_consensus_equals_host_vote(tmp_path):
+    """chiron_consensus_device (displacements + scan + vote + argmax + quality string on the GPU) against
+    the host path chiron_assemble -> np.argmax -> eval.qs: the reference's five example reads (segments/readN.fastq ->
+    result/readN.fastq, 43 390 bases, exact), random long reads with related and unrelated neighbours for glue and
+    stick, degenerate inputs, and `chiron call` forced onto the device vote."""
+    from chiron_amd import assembly, eval as ce
+    ex = os.path.join(GOLDEN, "example_dna")
+    total = 0
+    for i in range(1, 6):
+        segs = [l for l in open(os.path.join(ex, "segments", "read%d.fastq" % i)).read().split("\n")[1::2] if l]
+        want = open(os.path.join(ex, "result", "read%d.fastq" % i)).read().split("\n")[1]
+        got, q = assembly.consensus_device(segs, None, "glue")
+        assert got == want and q is None
+        total += len(got)
+    assert total == 43390
+    rng = np.random.RandomState(3)
+    for kernal in ("glue", "stick"):
+        for it in range(6):
+            n_seg = int(rng.choice([2, 3, 50, 3000, 20000]))
+            genome = rng.randint(0, 4, size=40 * n_seg + 500)
+            segs, pos = [], 0
+            for _ in range(n_seg):
+                ln = int(rng.randint(1, 60))
+                s = genome[pos:pos + ln].copy()
+                flip = rng.rand(len(s)) < 0.05
+                s[flip] = rng.randint(0, 4, size=int(flip.sum()))
+                segs.append("".join("ACGT"[v] for v in s))
+                pos += int(rng.randint(max(1, ln - 6), ln + 1)) if it % 2 == 0 else int(rng.randint(0, 70))
+            qsl = rng.uniform(0, 25, size=(n_seg, 1))
+            cons, cqs = assembly.simple_assembly_qs(segs, qsl, 0.975, kernal=kernal)
+            want_seq, want_q = ce.index2base(np.argmax(cons, axis=0)), ce.qs(cons, cqs)
+            got_seq, got_q = assembly.consensus_device(segs, qsl, kernal)
+            assert got_seq == want_seq, (kernal, it, n_seg)
+            assert got_q == want_q, (kernal, it, n_seg, [k for k in range(len(want_q)) if want_q[k] != got_q[k]][:5])
+            assert assembly.consensus_device(segs, None, kernal) == (want_seq, None)
+    assert assembly.consensus_device(["ACGT"], None, "glue") == ("", None)            # the reference's single-segment quirk
+    assert assembly.consensus_device([], None, "stick") == ("", None)
+    with pytest.raises(ValueError):
+        assembly.consensus_device(["ACGT", "ACGT"], None, "simple")
+    # chiron call with the threshold lowered: every read takes the device vote, output unchanged
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import shard_run
+    sig, model = str(tmp_path / "sig"), str(tmp_path / "model")
+    shard_run.write_reads(sig, 3, 40000)
+    shard_run.write_model_dir(model)
+    outs = []
+    for thr in (10 ** 9, 2):
+        class F(object):
+            input, output = sig, str(tmp_path / ("out%d" % thr))
+            start, batch_size, segment_len, jump, beam = 0, 300, 400, 390, 0
+            extension, concise, mode, recursive, synthetic_weights = "fastq", False, "dna", True, True
+            device_vote_min_segments = thr
+        F.model = model
+        ce.evaluation(F)
+        outs.append({n: open(os.path.join(F.output, "result", n)).read() for n in sorted(os.listdir(os.path.join(F.output, "result")))})
+    assert outs[0] == outs[1] and len(outs[0]) == 3
