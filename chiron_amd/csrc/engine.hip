@@ -138,6 +138,7 @@ struct BlockPlan {
   float *pwl_bp = nullptr, *pwl_ref = nullptr, *pwl_tab = nullptr, *pwl_shift = nullptr;
   int pwl_nbp = 0;
   ConvGemmPlan ga, gb, gc;                     // conv2a (non-lift), conv2b, conv2c(+conv1)
+  float* wino_u = nullptr;                     // conv2b as Winograd F(2,3) (wino.hip): transformed filters [4][C][C], or null
   // bn_mode = batch (cnn.py:166-188): the GEMM weights above are raw, gc holds conv2c alone, g1 the 1x1 branch1 conv;
   // scale / offset of the four BN sites (conv1 only when i_bn)
   ConvGemmPlan g1;
@@ -390,6 +391,22 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
         sh[n] = f2b.sh[n];
       }
       if ((st = upload_gemm(e, &bp.gb, Wt, sh, co, Npad, K))) return st;
+      // 1 x 3, stride 1 over C = co channels, fp32, population BN, even length: Winograd F(2,3) (wino.hip) -- four
+      // products per output pair instead of six.  U_j[n][c] in float64 from the folded taps g_tap = W2b[tap][c][n]*inv[n].
+      if (!bp.lift && !batch && !e->f16 && !e->split && b.k == 3 && b.stride == 1 && (t % 2) == 0 && co % 64 == 0 && ci == co &&
+          getenv("CHIRON_NO_WINOGRAD") == nullptr) {
+        std::vector<float> U((size_t)4 * co * co);
+        for (int n = 0; n < co; ++n)
+          for (int c = 0; c < co; ++c) {
+            const double g0 = (double)W2b[((size_t)0 * co + c) * co + n] * f2b.inv[n], g1 = (double)W2b[((size_t)1 * co + c) * co + n] * f2b.inv[n],
+                         g2 = (double)W2b[((size_t)2 * co + c) * co + n] * f2b.inv[n];
+            U[((size_t)0 * co + n) * co + c] = (float)g0;
+            U[((size_t)1 * co + n) * co + c] = (float)((g0 + g1 + g2) * 0.5);
+            U[((size_t)2 * co + n) * co + c] = (float)((g0 - g1 + g2) * 0.5);
+            U[((size_t)3 * co + n) * co + c] = (float)g2;
+          }
+        if ((st = dev_upload(e, &bp.wino_u, U))) return st;
+      }
     }
     if (bp.lift) {
       std::vector<float> la(cop, 0.f), lb(cop, 0.f), ra(Npad, 0.f);
@@ -752,7 +769,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     chiron_engine_destroy(e);
     return st;
   }
-  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res", "conv1_pwl"};
+  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res", "conv1_pwl", "conv_wino"};
   *out = e;
   return CHIRON_OK;
 }
@@ -785,7 +802,7 @@ extern "C" chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out
 // ----------------------------------------------------------------------------------------------
 // launch sequence
 // ----------------------------------------------------------------------------------------------
-enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES, PN_PWL };
+enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES, PN_PWL, PN_WINO };
 
 struct Prof {
   chiron_engine* e;
@@ -1015,8 +1032,19 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.out = bufB;
       g.ldo = b.c;
       {
-        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * (b.t_in + b.t_out) * b.c);
-        ok &= launch(e, g, s->stream);
+        bool done = false;
+        if (b.wino_u != nullptr) {
+          WinoParams wq;
+          wq.src = bufA, wq.U = b.wino_u, wq.shift = b.gb.shift, wq.out = bufB;
+          wq.B = B, wq.T = b.t_in, wq.C = b.c, wq.N = b.c, wq.lda = b.c, wq.ldo = b.c, wq.relu = 1;
+          // FLOPs of the convolution as the reference defines it (2 * 3 taps * C * C per position); 2/3 of them are executed
+          Prof pr(e, s, PN_WINO, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * (b.t_in + b.t_out) * b.c);
+          done = launch_wino_conv3(wq, s->stream);
+        }
+        if (!done) {
+          Prof pr(e, s, PN_CONV, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * (b.t_in + b.t_out) * b.c);
+          ok &= launch(e, g, s->stream);
+        }
       }
       // conv2c + branch1/conv1 fused along K, + ReLU
       init_gemm(&g, e, b.gc, B);

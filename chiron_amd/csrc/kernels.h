@@ -75,6 +75,16 @@ struct GemmParams {
 
 bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel for this shape / dtype
 
+// 1 x 3 stride-1 convolution in Winograd F(2,3) form (wino.hip): fp32, channels-last, T even, C % 32 == 0, N % 64 == 0
+struct WinoParams {
+  const float* src;    // [B*T][lda] activations
+  const float* U;      // [4][N][C] transformed filters (BN scale folded): g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2
+  const float* shift;  // [N] folded BN offset
+  float* out;          // [B*T][ldo]
+  int B, T, C, N, lda, ldo, relu;
+};
+bool launch_wino_conv3(const WinoParams& p, hipStream_t stream);  // false: shape not covered
+
 // ---------------------------------------------------------------------------------------------
 // LSTM recurrence (lstm.hip): one workgroup = 4*NG batch rows x one direction x all T steps.
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,268 @@
+// 1 x 3, stride-1 convolution over 256-wide channels-last activations (cnn.py:234-262: branch2/conv2b of the residual
+// blocks that follow the first one) in Winograd F(2,3) form on v_mfma_f32_32x32x2_f32.
+//
+// Two neighbouring output positions 2p, 2p+1 of one segment share their four input positions d0..d3 = x[2p-1 .. 2p+2]
+// (SAME padding: x[-1] = x[T] = 0).  With the filter taps g0, g1, g2 (BN scale folded in):
+//     m0 = (d0 - d2) g0            m1 = (d1 + d2) (g0 + g1 + g2)/2
+//     m2 = (d2 - d1) (g0 - g1 + g2)/2            m3 = (d1 - d3) g2
+//     y[2p] = m0 + m1 + m2         y[2p+1] = m1 - m2 - m3
+// -- four C x C products per position pair instead of six: 2/3 of the multiply-adds of the direct form.  Every GEMM of
+// the engine runs at the fp32 matrix-pipe limit (64 FLOP/clk/SIMD, the vector rate), so the only way to make this
+// layer faster is to execute fewer of them; the transforms cost two v_pk_add_f32 per operand quad next to 16 MFMAs.
+//
+//   workgroup tile: 128 position pairs (256 output rows) x 64 output channels, 8 waves as 4 x 2, each 32 pairs x 32
+//   channels x 4 products = 4 accumulators of 16 registers.  One persistent workgroup per CU (133 KB of LDS).
+//   Staging: LDS-DMA (buffer_load_dwordx4 ... lds, as gemm.hip), double buffered over the 8 channel chunks of 32.
+//   The four operands of a pair are rows of TWO halo tiles, not four: E[i] = x[even position of pair m0 + i] and
+//   O[i] = x[odd position of pair m0 - 1 + i], 129 rows each, so d1 = E[i], d3 = E[i+1], d0 = O[i], d2 = O[i+1]
+//   (the LDS-staged stencil: every input row is fetched once per tile and read by both pairs that need it).  A pair at
+//   the start / end of its segment must see the SAME padding zero instead of its neighbour segment's row: those two
+//   operands are read from a row of zeros (an address chosen once per tile, nothing per step).  Four filter tiles U_j
+//   complete a chunk: 34 + 32 one-KB DMA pieces per 512 MFMAs.
+//   Rows keep the XOR swizzle of gemm.hip (physical 16-byte slot = logical slot ^ ((row >> 1) & 7), applied on the
+//   source side), so a fragment read is one conflict-free ds_read_b128 feeding four MFMAs.
+//   Epilogue: the lane that owns pair p holds 16 channels of all four products: y[2p], y[2p+1] = combinations + shift,
+//   ReLU, two 16-byte stores per channel quad.
+// Differs from the direct form by fp32 rounding only (the transforms re-associate the sum over taps).
+#include "kernels.h"
+
+namespace chiron {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+namespace {
+
+constexpr int WP = 128;                 // position pairs per tile
+constexpr int WN = 64;                  // output channels per tile
+constexpr int WK = 32;                  // channels per chunk (128 bytes per row)
+constexpr int HALO_ROWS = 136;          // 129 rows used, 17 DMA pieces of 8 rows
+constexpr int HALO_F = HALO_ROWS * WK;  // floats per halo tile
+constexpr int U_F = WN * WK;            // floats per filter sub-tile
+constexpr int BUF_F = 2 * HALO_F + 4 * U_F;   // E, O, U0..U3: 66 KB per buffer
+constexpr unsigned OOB = 0xFFFF0000u;   // byte offset past num_records (+ any chunk offset): reads zeros
+constexpr unsigned RECORDS = 0xFFFE0000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, RECORDS, 0x00027000);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512, 2) void wino_conv3_kernel(const WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][BUF_F] tiles, one row of zeros, shift[N]
+  float* const zrow = lds + 2 * BUF_F;
+  float* const shl = zrow + WK;
+  const int tid = threadIdx.x;
+  if (p.C < 0) lds[tid] = 0.f;   // the tiles are only ever written by the DMA engine (see gemm.hip)
+  if (tid < WK) zrow[tid] = 0.f;
+  for (int n = tid; n < p.N; n += 512) shl[n] = p.shift[n];
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  const int half_t = p.T >> 1;                      // pairs per segment
+  const int mp = p.B * half_t;                      // pair rows in total
+  const int mblocks = (mp + WP - 1) / WP;
+  const int nblocks = p.N / WN;
+  const int total_ids = ((mblocks + 7) / 8) * 8 * nblocks;
+  const int chunks = p.C / WK;
+
+  auto tile_of = [&](int id, int& m0, int& n0) -> bool {   // XCD-aware: the N tiles of an M block share one XCD's L2
+    const int xcd = id & 7, slot = id >> 3;
+    const int mblk = (slot / nblocks) * 8 + xcd;
+    m0 = mblk * WP;
+    n0 = (slot % nblocks) * WN;
+    return mblk < mblocks;
+  };
+  auto next_valid = [&](int id) -> int {
+    int m0, n0;
+    do id += gridDim.x;
+    while (id < total_ids && !tile_of(id, m0, n0));
+    return id;
+  };
+
+  // ---- loader: a piece = 8 rows x 128 bytes; lane -> (row 8*piece + lane>>3, physical slot lane&7).
+  //      wave w loads pieces 2w, 2w+1 of E and of O, the 17th piece of E (wave 0) / O (wave 1), and pieces 4w .. 4w+3 of
+  //      the 32 filter pieces (sub-tile j = piece >> 3).
+  const __amdgpu_buffer_rsrc_t ra = rsrc_of(p.src), rb = rsrc_of(p.U);
+  unsigned eoff[3], ooff[3], boff[4];   // byte offsets of this lane's 16 bytes in chunk 0, or OOB
+  auto halo_off = [&](int m0, int row, int odd) -> unsigned {
+    const int slot = ((lane & 7) ^ ((row >> 1) & 7)) * 4;   // logical k-slot (floats) fetched into physical slot lane&7
+    const int pr = m0 + row - odd;                          // E[row] <- pair m0 + row (even position), O[row] <- pair m0 - 1 + row (odd)
+    if (pr < 0 || pr >= mp) return OOB;
+    const int b = pr / half_t, pp = pr - b * half_t;
+    return (unsigned)((((long)b * p.T + 2 * pp + odd) * p.lda + slot) * 4);
+  };
+  auto load_tile = [&](int id) {
+    int m0, n0;
+    tile_of(id, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int piece = i < 2 ? 2 * wave + i : 16;
+      const int row = 8 * piece + (lane >> 3);
+      eoff[i] = halo_off(m0, row, 0);
+      ooff[i] = halo_off(m0, row, 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = 4 * wave + i, j = piece >> 3;
+      const int row = 8 * (piece & 7) + (lane >> 3);
+      const int slot = ((lane & 7) ^ ((row >> 1) & 7)) * 4;
+      boff[i] = (unsigned)((((long)j * p.N + n0 + row) * p.C + slot) * 4);
+    }
+  };
+  // this wave's pieces of chunk c into buffer `dst`, in four parts so that they can be spread over the chunk's MFMA groups
+  // (a burst of nine DMA instructions stalls the wave that issues it; all waves of the CU share one address unit)
+  auto issue_part = [&](int part, int c, float* dst) {
+    const unsigned ck = (unsigned)(c * WK * 4);
+    if (part < 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(dst + (2 * wave + part) * 256), 16, eoff[part] + ck, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(dst + HALO_F + (2 * wave + part) * 256), 16, ooff[part] + ck, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(dst + 2 * HALO_F + (4 * wave + part) * 256), 16, boff[part] + ck, 0, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(dst + 2 * HALO_F + (4 * wave + part) * 256), 16, boff[part] + ck, 0, 0, 0);
+      if (part == 2 && wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(dst + 16 * 256), 16, eoff[2] + ck, 0, 0, 0);
+      if (part == 2 && wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(dst + HALO_F + 16 * 256), 16, ooff[2] + ck, 0, 0, 0);
+    }
+  };
+  auto issue = [&](int c, float* dst) {
+#pragma unroll
+    for (int part = 0; part < 4; ++part) issue_part(part, c, dst);
+  };
+
+  // fragment slots of this lane's rows: row r = wm*32 + li (E[r] = d1, O[r] = d0) and r + 1 (E = d3, O = d2)
+  int fs0[4], fs1[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    fs0[g] = ((2 * g + kh) ^ ((li >> 1) & 7)) * 4;
+    fs1[g] = ((2 * g + kh) ^ (((li + 1) >> 1) & 7)) * 4;
+  }
+
+  int c_id = blockIdx.x;
+  {
+    int m0, n0;
+    if (c_id >= total_ids) return;
+    if (!tile_of(c_id, m0, n0)) c_id = next_valid(c_id);
+    if (c_id >= total_ids) return;
+  }
+  load_tile(c_id);
+  issue(0, lds);
+  int buf = 0;
+  f32x16 acc[4];
+  bool have_prev = false;
+  int prev_pr = 0, prev_n0 = 0;
+  // y[2p], y[2p+1] of the finished tile: this lane owns pair `pr` and the channels n0 + wn*32 + 8q + 4kh + r (q, r = 0..3)
+  auto epilogue = [&](int pr, int n0) {
+    if (pr >= mp) return;
+    const int pb = pr / half_t, pp = pr - pb * half_t;
+    float* o0 = p.out + ((long)pb * p.T + 2 * pp) * p.ldo + n0 + wn * 32 + 4 * kh;
+    float* o1 = o0 + p.ldo;
+    const float* sh = shl + n0 + wn * 32 + 4 * kh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sh + 8 * q);
+      f32x4 y0, y1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a0 = acc[0][4 * q + r], a1 = acc[1][4 * q + r], a2 = acc[2][4 * q + r], a3 = acc[3][4 * q + r];
+        y0[r] = ((a0 + a1) + a2) + s4[r];
+        y1[r] = ((a1 - a2) - a3) + s4[r];
+        if (p.relu) {
+          y0[r] = __builtin_amdgcn_fmed3f(y0[r], 0.f, INFINITY);
+          y1[r] = __builtin_amdgcn_fmed3f(y1[r], 0.f, INFINITY);
+        }
+      }
+      *reinterpret_cast<f32x4*>(o0 + 8 * q) = y0;
+      *reinterpret_cast<f32x4*>(o1 + 8 * q) = y1;
+    }
+  };
+  while (c_id < total_ids) {
+    int m0, n0;
+    tile_of(c_id, m0, n0);
+    const int n_id = next_valid(c_id);
+    // this lane's pair: SAME padding at the ends of its segment comes from the row of zeros
+    const int pr = m0 + wm * 32 + li;
+    const int pp = pr % half_t;
+    const bool first = pp == 0, last = pp == half_t - 1;
+    for (int c = 0; c < chunks; ++c) {
+      __syncthreads();   // chunk c has landed in `buf` (vmcnt is drained before the barrier); buf ^ 1 is free
+      float* const nxt = lds + (buf ^ 1) * BUF_F;
+      const bool more = c + 1 < chunks;
+      const bool go = more || n_id < total_ids;
+      if (!more && go) load_tile(n_id);
+      const int nc = more ? c + 1 : 0;
+      if (c == 0) {
+        // the previous tile's stores are issued HERE, behind this tile's first barrier, so that no barrier ever waits for
+        // fresh stores; then the accumulators start from zero
+        if (have_prev) epilogue(prev_pr, prev_n0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+      }
+      const float* t0 = lds + buf * BUF_F;
+      const int r0 = (wm * 32 + li) * WK;
+      const float* e0 = t0 + r0;                                   // d1
+      const float* e1 = last ? zrow - fs1[0] : t0 + r0 + WK;       // d3 (the zero row is read at offset 0..28: any slot is zero)
+      const float* o0 = first ? zrow - fs0[0] : t0 + HALO_F + r0;  // d0
+      const float* o1 = t0 + HALO_F + r0 + WK;                     // d2
+      const float* brow = t0 + 2 * HALO_F + (wn * 32 + li) * WK;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(e0 + fs0[g]);
+        const f32x4 d3 = *reinterpret_cast<const f32x4*>(e1 + (last ? fs1[0] : fs1[g]));
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(o0 + (first ? fs0[0] : fs0[g]));
+        const f32x4 d2 = *reinterpret_cast<const f32x4*>(o1 + fs1[g]);
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(brow + 0 * U_F + fs0[g]);
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(brow + 1 * U_F + fs0[g]);
+        const f32x4 u2 = *reinterpret_cast<const f32x4*>(brow + 2 * U_F + fs0[g]);
+        const f32x4 u3 = *reinterpret_cast<const f32x4*>(brow + 3 * U_F + fs0[g]);
+        const f32x4 v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;
+        if (go) issue_part(g, nc, nxt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[j], v0[j], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[j], v1[j], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2[j], v2[j], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u3[j], v3[j], acc[3], 0, 0, 0);
+        }
+      }
+      buf ^= 1;
+    }
+    have_prev = true;
+    prev_pr = pr;
+    prev_n0 = n0;
+    c_id = n_id;
+  }
+  if (have_prev) epilogue(prev_pr, prev_n0);
+}
+
+bool launch_wino_conv3(const WinoParams& p, hipStream_t stream) {
+  if (p.T <= 0 || (p.T & 1) || p.C <= 0 || (p.C % WK) || p.N <= 0 || (p.N % WN) || p.N > 1024) return false;
+  if ((size_t)p.B * p.T * (size_t)p.lda * 4 > RECORDS) return false;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const size_t lds_bytes = (size_t)(2 * BUF_F + WK + p.N) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    attr_set = true;
+  }
+  const int half_t = p.T / 2;
+  const int mblocks = (p.B * half_t + WP - 1) / WP;
+  const int total_ids = ((mblocks + 7) / 8) * 8 * (p.N / WN);
+  int g = (n_cu / 8) * 8;
+  if (g > total_ids) g = total_ids;
+  hipLaunchKernelGGL(wino_conv3_kernel, dim3(g), dim3(512), lds_bytes, stream, p);
+  return true;
+}
+
+}  // namespace chiron

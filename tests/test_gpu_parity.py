@@ -369,6 +369,36 @@ def test_paired_recurrence_workgroups_give_identical_bits(dna, monkeypatch):
     assert np.abs(out[0][rows] - ref).max() < TOL
 
 
+def test_winograd_conv2b_against_direct_form_and_oracle(dna, rna, monkeypatch):
+    """wino.hip: conv2b of the blocks after the first one as Winograd F(2,3) (4 products per output pair instead of 6).
+    Same function re-associated: logits within 3e-5 of the direct-form engine (CHIRON_NO_WINOGRAD=1) and within the 1e-4
+    bound of the float64 oracle; window boundaries inside a tile (SAME padding zeros at both ends of every segment),
+    ragged and empty rows, a batch that does not fill the last tile, and the RNA graph (T = 100).  An odd length has no
+    pairs: the engine then runs the direct form (identical bits with and without the switch)."""
+    from oracle import nn_oracle
+    for (spec, w), L, B in ((dna, 400, 37), (dna, 64, 5), (rna, 500, 21), (dna, 399, 6)):
+        x, ln = _windows(L * B, L, L, seed=77 + L)
+        x, ln = x[:B], ln[:B].copy()
+        ln[1] = 0
+        ln[B - 1] = L // 3
+        outs = []
+        for direct in (False, True):
+            if direct:
+                monkeypatch.setenv("CHIRON_NO_WINOGRAD", "1")
+            else:
+                monkeypatch.delenv("CHIRON_NO_WINOGRAD", raising=False)
+            with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
+                sl = ca.seq_len_for_engine(ln, eng.ratio)
+                outs.append(eng.infer(x, sl, want_logits=True).logits.copy())
+        monkeypatch.delenv("CHIRON_NO_WINOGRAD", raising=False)
+        if spec.output_len(L) % 2 or L == 399:
+            assert np.array_equal(outs[0], outs[1])
+        else:
+            assert 0 < np.abs(outs[0] - outs[1]).max() < 3e-5
+        ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+        assert np.abs(outs[0] - ref).max() < TOL and np.abs(outs[1] - ref).max() < TOL
+
+
 def _beam_rows(res, B):
     got = [[] for _ in range(B)]
     for (r, _), v in zip(res.decoded.indices, res.decoded.values):
