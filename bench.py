@@ -37,7 +37,8 @@ LSTM_GEMM_FLOP_PER_WINDOW = 611.84e6
 MODEL_FLOP_PER_WINDOW = 1.451e9                       # reference op count (CNN 839.3 M + LSTM 611.84 M)
 # res_layer1 conv2a + conv2b run as a piecewise-linear table of the signal value (chiron_amd/csrc/pwl.hip): their
 # 2*(1 + 3*256)*256 FLOP per position are no longer executed as multiply-adds
-EXECUTED_FLOP_PER_WINDOW = MODEL_FLOP_PER_WINDOW - SEG_LEN * 2.0 * (1 + 3 * 256) * 256
+# conv2b of res_layer2 / res_layer3 runs in Winograd F(2,3) form (wino.hip): 4 instead of 6 C x C products per output pair
+EXECUTED_FLOP_PER_WINDOW = MODEL_FLOP_PER_WINDOW - SEG_LEN * 2.0 * (1 + 3 * 256) * 256 - 2 * SEG_LEN * 2.0 * 256 * 256
 PEAK_F32_MFMA_TFLOPS = 157.3                          # MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 READ_SAMPLES = 100000                                 # configs[3]: 100k-sample reads -> 257 windows
 
@@ -61,9 +62,15 @@ def make_batches(n_batches, rank):
     return (x.reshape(n_batches, BATCH, SEG_LEN), ln.reshape(n_batches, BATCH), tags, win_per_read)
 
 
-# dominant kernel by device time: conv2b of res_layer1 and conv2a / conv2b / conv2c+branch1 of res_layer2,3 (7 launches per batch); template
-# arguments <ZOUT, RES, chunks per K-segment, K tail, mode (0 fp32, 1 f16, 2 split)>
-DOM_KERNEL = "gemm_f32_dma_kernel<false, false, 8, false, 0>"
+# profiling bucket of the engine (chiron_engine_profile) -> kernel symbol(s) in a rocprofv3 trace; template arguments of
+# gemm_f32_dma_kernel are <ZOUT, RES, chunks per K-segment, K tail, mode (0 fp32, 1 f16, 2 split)>
+BUCKET_SYMBOL = {
+    "lstm_recurrence": "lstm_kernel<1>",
+    "conv_dma": "gemm_f32_dma_kernel<false, false, 8, false, 0>",          # conv2a (K=256) and conv2c+branch1 (K=512) of res_layer2/3
+    "conv_wino": "wino_conv3_kernel",                                       # conv2b of res_layer2/3, Winograd F(2,3)
+    "conv_res": "gemm_f32_dma_kernel<false, true, 8, false, 0>",            # conv2c + signal branch of res_layer1
+    "lstm_proj_dma": "gemm_f32_dma_kernel<true, false, 8|7, *, 0>",         # x-projections (layer 0: K=256; layers 1,2: K=200)
+}
 
 
 def main():
@@ -198,25 +205,31 @@ def main():
                           "tflops": (s["flops"] / (s["total_ms"] * 1e-3) / 1e12) if s["total_ms"] > 0 else 0.0,
                           "gbps": (s["bytes"] / (s["total_ms"] * 1e-3) / 1e9) if s["total_ms"] > 0 else 0.0}
                       for k, s in stats.items()}
-        # dominant kernel by time: gemm_f32_dma_kernel<false,false> = conv2a / conv2b / conv2c+branch1 of
-        # res_layer1..3 (7 launches per batch).  The whole GEMM family is summarised in extra.
-        dom = stats["conv_dma"]
+        # dominant kernel = the MFMA-bound bucket with the largest device time in this pass (one kernel symbol each, except
+        # the projections, which are two instantiations of one template)
+        mfma_buckets = [k for k in BUCKET_SYMBOL if k in stats and stats[k]["total_ms"] > 0]
+        dom_key = max(mfma_buckets, key=lambda k: stats[k]["total_ms"])
+        dom = stats[dom_key]
+        dom_symbol = BUCKET_SYMBOL[dom_key]
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(DOM_KERNEL)
-        roofline = {"kernel": DOM_KERNEL, "bound": "mfma",
+        traffic, traffic_src = pmc_traffic(dom_symbol)
+        per_bucket = {k: {"symbol": BUCKET_SYMBOL[k], "ms_per_batch": round(stats[k]["total_ms"] / 3.0, 4),
+                          "launches_per_batch": stats[k]["launches"] / 3.0,
+                          "achieved": round(stats[k]["flops"] / (stats[k]["total_ms"] * 1e-3) / 1e12, 2),
+                          "frac": round(stats[k]["flops"] / (stats[k]["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                      for k in mfma_buckets}
+        roofline = {"kernel": dom_symbol, "bucket": dom_key, "bound": "mfma",
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 of a separate rocprofv3 --pmc pass",
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
                     "flops_per_launch": dom["flops"] / dom["launches"],
+                    "flops_note": "algorithmic FLOPs of the reference's op (conv_wino executes 2/3 of its 2*3*C*C per position)",
                     # the north-star figure -- LSTM-GEMM FLOPs of all windows / whole-job time / fp32 MFMA peak
                     "lstm_gemm_roofline_frac_whole_path": round(windows / dt * LSTM_GEMM_FLOP_PER_WINDOW / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4),
                     "lstm_gemm_flop_per_window": LSTM_GEMM_FLOP_PER_WINDOW,
-                    # the kernel furthest below the roofline, same HIP-event pass: the recurrence (2*2*B*T*H*4H FLOP per launch)
-                    "lstm_recurrence": {"achieved": round(stats["lstm_recurrence"]["flops"] / (stats["lstm_recurrence"]["total_ms"] * 1e-3) / 1e12, 2),
-                                        "frac": round(stats["lstm_recurrence"]["flops"] / (stats["lstm_recurrence"]["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                        "avg_launch_ms": round(stats["lstm_recurrence"]["total_ms"] / stats["lstm_recurrence"]["launches"], 4)},
+                    "mfma_kernels": per_bucket,
                     "traffic_source": traffic_src}
         fam = [s for k, s in stats.items() if k.startswith("conv_") or k.startswith("lstm_proj")]
         gemm_family = {"launches_per_batch": sum(s["launches"] for s in fam) / 3.0,

@@ -399,6 +399,38 @@ def test_winograd_conv2b_against_direct_form_and_oracle(dna, rna, monkeypatch):
         assert np.abs(outs[0] - ref).max() < TOL and np.abs(outs[1] - ref).max() < TOL
 
 
+def test_saturated_gates_and_extreme_preactivations(dna):
+    """The recurrence evaluates sigmoid / tanh on the hardware exp2 / rcp (lstm.hip lstm_cell) instead of libm's expf /
+    tanhf.  With the default synthetic weights the gates live in their linear region; trained models do not.  Gate biases
+    of +-50 .. +-120 saturate the sigmoids completely -- 2^(+-170) and inf / 0 intermediates inside the formulas must
+    still give exactly 0 and 1 -- with the cell written through, frozen, integrating without output, or held; a tiny
+    kernel gain puts every gate at its midpoint.  Logits must stay within the fp32 bound of the float64 oracle, no NaN /
+    inf."""
+    from oracle import nn_oracle
+    spec, _ = dna
+    L, B, H = 400, 12, 100
+    x, ln = _windows(390 * (B - 1) + 200, L, 390, seed=61)
+    # (i, f, o) biases.  All three open at once is left out on purpose: the cell then integrates 400 steps of +-1 through
+    # a recurrent loop of gain ~1 and fp32 / fp64 restatements of the SAME formulas drift apart by 0.5 (measured with the
+    # numpy oracle at both precisions): sensitivity of the network, not of an implementation.
+    cases = {"write-through": (50.0, -50.0, 50.0), "closed": (-50.0, -50.0, -50.0), "integrate-no-output": (120.0, 80.0, -90.0),
+             "hold-and-output": (-50.0, 50.0, 50.0), "midpoint": "tiny"}
+    for name, gates in cases.items():
+        w = ca.synthetic_weights(spec, seed=9) if gates != "tiny" else ca.synthetic_weights(spec, seed=9, lstm_gain=1e-3)
+        if gates != "tiny":
+            for k in w:
+                if k.endswith("lstm_cell/bias"):
+                    b = w[k]                     # columns i | j | f | o
+                    b[0:H], b[2 * H:3 * H], b[3 * H:4 * H] = gates
+        with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
+            sl = ca.seq_len_for_engine(ln, eng.ratio)
+            got = eng.infer(x, sl, want_logits=True).logits
+        ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+        assert np.isfinite(got).all(), name
+        err = np.abs(got - ref).max()
+        assert err < TOL, (name, err)
+
+
 def _beam_rows(res, B):
     got = [[] for _ in range(B)]
     for (r, _), v in zip(res.decoded.indices, res.decoded.values):
@@ -711,6 +743,50 @@ def test_f16_path_tolerance_vs_f32(dna, rna):
             if a != b:
                 sm = difflib.SequenceMatcher(None, a, b, autojunk=False)
                 assert max(len(a), len(b)) - sum(m.size for m in sm.get_matching_blocks()) <= 2
+
+
+def _levenshtein(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca_ in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca_ != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def test_f16_config5_full_batch_edit_distance_distribution(dna):
+    """BASELINE configs[4] at its real size: DNA_default, fp16 conv + LSTM / fp32 CTC, batch 4096, against the fp32 engine
+    on the same 4096 windows.  Reported, not tuned to pass: the distribution of the per-window edit distance between the
+    two greedy base strings (written to gpurun_out/f16_edit_distance.json when that folder exists) and the logits
+    deviation.  Asserted: what the distribution measured on this workload supports with margin -- at least 95 % of the
+    windows identical, at most 1 % more than one edit apart, none more than four, mean below 0.06 edits per window
+    (a window decodes to ~45 bases), logits within 0.08."""
+    import json
+    spec, w = dna
+    L, B = 400, 4096
+    x, ln = _windows(390 * (B - 1) + 77, L, 390, seed=45)
+    assert x.shape[0] == B
+    with ca.Engine(spec, w, max_batch=B, segment_len=L) as e32:
+        sl = ca.seq_len_for_engine(ln, e32.ratio)
+        r32 = e32.infer(x, sl, want_logits=True)
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, dtype="fp16") as e16:
+        r16 = e16.infer(x, sl, want_logits=True)
+    rows32, rows16 = _beam_rows(r32, B), _beam_rows(r16, B)
+    dist = np.array([0 if a == b else _levenshtein(a, b) for a, b in zip(rows16, rows32)])
+    hist = {int(k): int(v) for k, v in zip(*np.unique(dist, return_counts=True))}
+    T = r32.logits.shape[1]
+    mask = np.arange(T)[None, :] < sl[:, None]
+    dl = np.abs(r16.logits - r32.logits)[mask]
+    report = {"windows": B, "bases_fp32": int(sum(len(r) for r in rows32)), "edit_distance_histogram": hist,
+              "identical_fraction": float((dist == 0).mean()), "mean_edits_per_window": float(dist.mean()),
+              "logits_max_abs": float(dl.max()), "logits_mean_abs": float(dl.mean()), "logits_p999_abs": float(np.quantile(dl, 0.999))}
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        json.dump(report, open(os.path.join(out_dir, "f16_edit_distance.json"), "w"), indent=1)
+    print(json.dumps(report))
+    assert report["identical_fraction"] >= 0.95 and (dist > 1).mean() <= 0.01 and dist.max() <= 4 and dist.mean() < 0.06, report
+    assert report["logits_max_abs"] < 0.08, report
 
 
 def test_predict_signature_served_from_the_engine(dna):
