@@ -69,7 +69,8 @@ BUCKET_SYMBOL = {
     "conv_dma": "gemm_f32_dma_kernel<false, false, 8, false, 0>",          # conv2a (K=256) and conv2c+branch1 (K=512) of res_layer2/3
     "conv_wino": "wino_conv3_kernel",                                       # conv2b of res_layer2/3, Winograd F(2,3)
     "conv_res": "gemm_f32_dma_kernel<false, true, 8, false, 0>",            # conv2c + signal branch of res_layer1
-    "lstm_proj_dma": "gemm_f32_dma_kernel<true, false, 8|7, *, 0>",         # x-projections (layer 0: K=256; layers 1,2: K=200)
+    "lstm_proj0_dma": "gemm_f32_dma_kernel<true, false, 8, false, 0>",      # x-projection of layer 0 (K = 256)
+    "lstm_proj_dma": "gemm_f32_dma_kernel<true, false, 7, true, 0>",        # x-projections of layers 1, 2 (K = 200)
 }
 
 
@@ -205,8 +206,7 @@ def main():
                           "tflops": (s["flops"] / (s["total_ms"] * 1e-3) / 1e12) if s["total_ms"] > 0 else 0.0,
                           "gbps": (s["bytes"] / (s["total_ms"] * 1e-3) / 1e9) if s["total_ms"] > 0 else 0.0}
                       for k, s in stats.items()}
-        # dominant kernel = the MFMA-bound bucket with the largest device time in this pass (one kernel symbol each, except
-        # the projections, which are two instantiations of one template)
+        # dominant kernel = the MFMA-bound bucket (= one kernel symbol) with the largest device time in this pass
         mfma_buckets = [k for k in BUCKET_SYMBOL if k in stats and stats[k]["total_ms"] > 0]
         dom_key = max(mfma_buckets, key=lambda k: stats[k]["total_ms"])
         dom = stats[dom_key]

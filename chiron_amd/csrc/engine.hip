@@ -769,7 +769,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     chiron_engine_destroy(e);
     return st;
   }
-  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res", "conv1_pwl", "conv_wino"};
+  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res", "conv1_pwl", "conv_wino", "lstm_proj0_dma"};
   *out = e;
   return CHIRON_OK;
 }
@@ -802,7 +802,7 @@ extern "C" chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out
 // ----------------------------------------------------------------------------------------------
 // launch sequence
 // ----------------------------------------------------------------------------------------------
-enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES, PN_PWL, PN_WINO };
+enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES, PN_PWL, PN_WINO, PN_PROJ0 };
 
 struct Prof {
   chiron_engine* e;
@@ -1099,7 +1099,8 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
       g.z_seq_len = s->seq;
       g.z_f16 = e->f16 ? 1 : 0;
       const double ndir = lp.nproj == 1 ? 2.0 : 1.0;
-      Prof pr(e, s, PN_PROJ, 2.0 * B * T * (double)lp.in_w * 4 * H * ndir, 4.0 * B * T * (lp.in_w + ndir * zc));
+      // layer 0 reads the CNN features (K = 256: its own kernel instantiation), the other layers the recurrent output
+      Prof pr(e, s, l == 0 ? PN_PROJ0 : PN_PROJ, 2.0 * B * T * (double)lp.in_w * 4 * H * ndir, 4.0 * B * T * (lp.in_w + ndir * zc));
       ok &= launch(e, g, s->stream);
     }
     LstmParams r;
