@@ -138,7 +138,8 @@ struct BlockPlan {
   float *pwl_bp = nullptr, *pwl_ref = nullptr, *pwl_tab = nullptr, *pwl_shift = nullptr;
   int pwl_nbp = 0;
   ConvGemmPlan ga, gb, gc;                     // conv2a (non-lift), conv2b, conv2c(+conv1)
-  float* wino_u = nullptr;                     // conv2b as Winograd F(2,3) (wino.hip): transformed filters [4][C][C], or null
+  float* wino_u = nullptr;                     // conv2b in Winograd form (wino.hip): transformed filters [4 or 6][C][C], or null
+  int wino_f4 = 0;                             // 1: F(4,3) (six filters, length % 4 == 0), 0: F(2,3)
   // bn_mode = batch (cnn.py:166-188): the GEMM weights above are raw, gc holds conv2c alone, g1 the 1x1 branch1 conv;
   // scale / offset of the four BN sites (conv1 only when i_bn)
   ConvGemmPlan g1;
@@ -395,16 +396,23 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       // products per output pair instead of six.  U_j[n][c] in float64 from the folded taps g_tap = W2b[tap][c][n]*inv[n].
       if (!bp.lift && !batch && !e->f16 && !e->split && b.k == 3 && b.stride == 1 && (t % 2) == 0 && co % 64 == 0 && ci == co &&
           getenv("CHIRON_NO_WINOGRAD") == nullptr) {
-        std::vector<float> U((size_t)4 * co * co);
+        const bool f4 = (t % 4) == 0 && getenv("CHIRON_WINOGRAD_F2") == nullptr;
+        const int nu = f4 ? 6 : 4;
+        // F(4,3): U = G g;  F(2,3): g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2
+        static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                        {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+        static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        std::vector<float> U((size_t)nu * co * co);
         for (int n = 0; n < co; ++n)
           for (int c = 0; c < co; ++c) {
-            const double g0 = (double)W2b[((size_t)0 * co + c) * co + n] * f2b.inv[n], g1 = (double)W2b[((size_t)1 * co + c) * co + n] * f2b.inv[n],
-                         g2 = (double)W2b[((size_t)2 * co + c) * co + n] * f2b.inv[n];
-            U[((size_t)0 * co + n) * co + c] = (float)g0;
-            U[((size_t)1 * co + n) * co + c] = (float)((g0 + g1 + g2) * 0.5);
-            U[((size_t)2 * co + n) * co + c] = (float)((g0 - g1 + g2) * 0.5);
-            U[((size_t)3 * co + n) * co + c] = (float)g2;
+            double gt[3];
+            for (int tap = 0; tap < 3; ++tap) gt[tap] = (double)W2b[((size_t)tap * co + c) * co + n] * f2b.inv[n];
+            for (int j = 0; j < nu; ++j) {
+              const double* gj = f4 ? G4[j] : G2[j];
+              U[((size_t)j * co + n) * co + c] = (float)(gj[0] * gt[0] + gj[1] * gt[1] + gj[2] * gt[2]);
+            }
           }
+        bp.wino_f4 = f4 ? 1 : 0;
         if ((st = dev_upload(e, &bp.wino_u, U))) return st;
       }
     }
@@ -1036,7 +1044,7 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
         if (b.wino_u != nullptr) {
           WinoParams wq;
           wq.src = bufA, wq.U = b.wino_u, wq.shift = b.gb.shift, wq.out = bufB;
-          wq.B = B, wq.T = b.t_in, wq.C = b.c, wq.N = b.c, wq.lda = b.c, wq.ldo = b.c, wq.relu = 1;
+          wq.B = B, wq.T = b.t_in, wq.C = b.c, wq.N = b.c, wq.lda = b.c, wq.ldo = b.c, wq.relu = 1, wq.f4 = b.wino_f4;
           // FLOPs of the convolution as the reference defines it (2 * 3 taps * C * C per position); 2/3 of them are executed
           Prof pr(e, s, PN_WINO, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * (b.t_in + b.t_out) * b.c);
           done = launch_wino_conv3(wq, s->stream);

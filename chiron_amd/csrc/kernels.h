@@ -78,10 +78,12 @@ bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel 
 // 1 x 3 stride-1 convolution in Winograd F(2,3) form (wino.hip): fp32, channels-last, T even, C % 32 == 0, N % 64 == 0
 struct WinoParams {
   const float* src;    // [B*T][lda] activations
-  const float* U;      // [4][N][C] transformed filters (BN scale folded): g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2
+  const float* U;      // F(2,3): [4][N][C] transformed filters (BN scale folded): g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2;
+                       // F(4,3) (f4 = 1): [6][N][C] = G g
   const float* shift;  // [N] folded BN offset
   float* out;          // [B*T][ldo]
   int B, T, C, N, lda, ldo, relu;
+  int f4;              // 1: F(4,3) (T % 4 == 0), 0: F(2,3) (T % 2 == 0)
 };
 bool launch_wino_conv3(const WinoParams& p, hipStream_t stream);  // false: shape not covered
 

@@ -370,65 +370,42 @@ def test_paired_recurrence_workgroups_give_identical_bits(dna, monkeypatch):
 
 
 def test_winograd_conv2b_against_direct_form_and_oracle(dna, rna, monkeypatch):
-    """wino.hip: conv2b of the blocks after the first one as Winograd F(2,3) (4 products per output pair instead of 6).
-    Same function re-associated: logits within 3e-5 of the direct-form engine (CHIRON_NO_WINOGRAD=1) and within the 1e-4
-    bound of the float64 oracle; window boundaries inside a tile (SAME padding zeros at both ends of every segment),
-    ragged and empty rows, a batch that does not fill the last tile, and the RNA graph (T = 100).  An odd length has no
-    pairs: the engine then runs the direct form (identical bits with and without the switch)."""
+    """wino.hip: conv2b of the blocks after the first one in Winograd form -- F(4,3) when the length is a multiple of 4
+    (6 products per 4 outputs instead of 12), F(2,3) when it is only even (4 per 2 instead of 6; also forced with
+    CHIRON_WINOGRAD_F2=1), the direct form otherwise (CHIRON_NO_WINOGRAD=1 forces it).  Same function re-associated:
+    logits within 3e-5 of the direct-form engine and within the 1e-4 bound of the float64 oracle; segment boundaries
+    inside a tile (SAME padding zeros at both ends of every segment), ragged and empty rows, a batch that does not fill
+    the last tile, and the RNA graph (T = 100).  An odd length runs the direct form: identical bits with and without
+    the switches."""
     from oracle import nn_oracle
-    for (spec, w), L, B in ((dna, 400, 37), (dna, 64, 5), (rna, 500, 21), (dna, 399, 6)):
+    for (spec, w), L, B, form in ((dna, 400, 37, "f4"), (dna, 64, 5, "f4"), (rna, 500, 21, "f4"), (dna, 398, 9, "f2"), (dna, 399, 6, "direct")):
         x, ln = _windows(L * B, L, L, seed=77 + L)
         x, ln = x[:B], ln[:B].copy()
         ln[1] = 0
         ln[B - 1] = L // 3
-        outs = []
-        for direct in (False, True):
-            if direct:
-                monkeypatch.setenv("CHIRON_NO_WINOGRAD", "1")
-            else:
-                monkeypatch.delenv("CHIRON_NO_WINOGRAD", raising=False)
+        outs = {}
+        for mode, env in (("default", None), ("f2", "CHIRON_WINOGRAD_F2"), ("direct", "CHIRON_NO_WINOGRAD")):
+            for v in ("CHIRON_WINOGRAD_F2", "CHIRON_NO_WINOGRAD"):
+                monkeypatch.delenv(v, raising=False)
+            if env:
+                monkeypatch.setenv(env, "1")
             with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
                 sl = ca.seq_len_for_engine(ln, eng.ratio)
-                outs.append(eng.infer(x, sl, want_logits=True).logits.copy())
-        monkeypatch.delenv("CHIRON_NO_WINOGRAD", raising=False)
-        if spec.output_len(L) % 2 or L == 399:
-            assert np.array_equal(outs[0], outs[1])
+                outs[mode] = eng.infer(x, sl, want_logits=True).logits.copy()
+        for v in ("CHIRON_WINOGRAD_F2", "CHIRON_NO_WINOGRAD"):
+            monkeypatch.delenv(v, raising=False)
+        if form == "direct":
+            assert np.array_equal(outs["default"], outs["direct"]) and np.array_equal(outs["f2"], outs["direct"])
         else:
-            assert 0 < np.abs(outs[0] - outs[1]).max() < 3e-5
+            assert 0 < np.abs(outs["default"] - outs["direct"]).max() < 3e-5
+            assert 0 < np.abs(outs["f2"] - outs["direct"]).max() < 3e-5
+            if form == "f4":
+                assert not np.array_equal(outs["default"], outs["f2"])       # the default really took the F(4,3) kernel
+            else:
+                assert np.array_equal(outs["default"], outs["f2"])
         ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
-        assert np.abs(outs[0] - ref).max() < TOL and np.abs(outs[1] - ref).max() < TOL
-
-
-def test_saturated_gates_and_extreme_preactivations(dna):
-    """The recurrence evaluates sigmoid / tanh on the hardware exp2 / rcp (lstm.hip lstm_cell) instead of libm's expf /
-    tanhf.  With the default synthetic weights the gates live in their linear region; trained models do not.  Gate biases
-    of +-50 .. +-120 saturate the sigmoids completely -- 2^(+-170) and inf / 0 intermediates inside the formulas must
-    still give exactly 0 and 1 -- with the cell written through, frozen, integrating without output, or held; a tiny
-    kernel gain puts every gate at its midpoint.  Logits must stay within the fp32 bound of the float64 oracle, no NaN /
-    inf."""
-    from oracle import nn_oracle
-    spec, _ = dna
-    L, B, H = 400, 12, 100
-    x, ln = _windows(390 * (B - 1) + 200, L, 390, seed=61)
-    # (i, f, o) biases.  All three open at once is left out on purpose: the cell then integrates 400 steps of +-1 through
-    # a recurrent loop of gain ~1 and fp32 / fp64 restatements of the SAME formulas drift apart by 0.5 (measured with the
-    # numpy oracle at both precisions): sensitivity of the network, not of an implementation.
-    cases = {"write-through": (50.0, -50.0, 50.0), "closed": (-50.0, -50.0, -50.0), "integrate-no-output": (120.0, 80.0, -90.0),
-             "hold-and-output": (-50.0, 50.0, 50.0), "midpoint": "tiny"}
-    for name, gates in cases.items():
-        w = ca.synthetic_weights(spec, seed=9) if gates != "tiny" else ca.synthetic_weights(spec, seed=9, lstm_gain=1e-3)
-        if gates != "tiny":
-            for k in w:
-                if k.endswith("lstm_cell/bias"):
-                    b = w[k]                     # columns i | j | f | o
-                    b[0:H], b[2 * H:3 * H], b[3 * H:4 * H] = gates
-        with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
-            sl = ca.seq_len_for_engine(ln, eng.ratio)
-            got = eng.infer(x, sl, want_logits=True).logits
-        ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
-        assert np.isfinite(got).all(), name
-        err = np.abs(got - ref).max()
-        assert err < TOL, (name, err)
+        for mode in outs:
+            assert np.abs(outs[mode] - ref).max() < TOL, mode
 
 
 def _beam_rows(res, B):
