@@ -15,7 +15,7 @@ import chiron_amd as ca
 from chiron_amd import signal_io
 
 
-def run(name, spec, L, jump, B, beam, steps=6, dtype="fp32"):
+def run(name, spec, L, jump, B, beam, steps=20, dtype="fp32"):
     w = ca.synthetic_weights(spec, seed=1234)
     sig = ca.synthetic_signal(1, jump * (B - 1) + L, seed=5)[0]
     x, ln = signal_io.window_signal(sig, 0, jump, L)
@@ -63,7 +63,7 @@ if __name__ == "__main__":
         for B in [int(v) for v in sys.argv[2:]]:
             run("DNA_default seg400 jump390 b%d greedy" % B, ca.dna_default_spec(), 400, 390, B, 0, steps=4)
         sys.exit(0)
-    run("RNA_default seg500 jump490 b400 beam50", ca.rna_default_spec(), 500, 490, 400, 50)
+    run("RNA_default seg500 jump490 b400 beam50", ca.rna_default_spec(), 500, 490, 400, 50, steps=100)   # 2 ms steps: 100 of them
     run("DNA_default seg400 jump390 b1100 beam30", ca.dna_default_spec(), 400, 390, 1100, 30)
     run("DNA_default seg400 jump390 b1100 beam50", ca.dna_default_spec(), 400, 390, 1100, 50)
     run("DNA_default seg400 jump390 b1100 greedy", ca.dna_default_spec(), 400, 390, 1100, 0)

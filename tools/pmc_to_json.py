@@ -17,7 +17,9 @@ def family(name):
         return n.replace("void ", "").replace("chiron::", "").strip()
     if "lstm_kernel<" in n:
         return n.replace("void ", "").replace("chiron::", "").strip()
-    for key in ("wino_conv3_kernel", "pwl_conv_kernel", "lstm16_kernel", "lstm_kernel", "fc_kernel", "beam64_kernel", "greedy_kernel", "beam_kernel", "scan_kernel", "scatter_kernel"):
+    if "wino_conv3" in n:
+        return n.replace("void ", "").replace("chiron::", "").strip()
+    for key in ("pwl_conv_kernel", "lstm16_kernel", "lstm_kernel", "fc_kernel", "beam64_kernel", "greedy_kernel", "beam_kernel", "scan_kernel", "scatter_kernel"):
         if key in n:
             return key
     return None
