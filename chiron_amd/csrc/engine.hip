@@ -213,6 +213,7 @@ struct chiron_engine {
   chiron_engine_opts opts;
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
+  bool lstm_fixed_roles = false;  // A/B switch: light role always on wave 6
   bool lstm_paired = false;  // fp32 recurrence: 14-wave workgroups for the part of a batch that fits one resident round
   bool bn_batch = false;  // desc.bn_mode == CHIRON_BN_BATCH
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
@@ -766,6 +767,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   // faster per resident round, but they fill their CU: with several batches in flight the 7-wave form, which shares a CU
   // with another slot's GEMM workgroups, gives the higher throughput (3905 vs 4004 kbases/s on one box).
   e->lstm_paired = getenv("CHIRON_LSTM_PAIR") != nullptr;
+  e->lstm_fixed_roles = getenv("CHIRON_LSTM_FIXED_ROLES") != nullptr;
   st = build_plans(e, weights);
   if (st == CHIRON_OK) {
     e->slots.resize(e->opts.n_slots);
@@ -1123,6 +1125,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.H = H;
     r.ndir = 2;
     r.paired = e->lstm_paired ? 1 : 0;
+    r.fixed_roles = e->lstm_fixed_roles ? 1 : 0;
     r.group0 = 0;
     r.f16 = e->f16 ? 1 : 0;
     {

@@ -104,6 +104,7 @@ struct LstmParams {
   int T, B, BP, H;
   int ndir;              // 2
   int paired;            // fp32: 1 = 14-wave workgroups (two groups per CU) for the part of the batch that fits one resident round
+  int fixed_roles;       // fp32: 1 = wave 6 is always the light wave (A/B switch CHIRON_LSTM_FIXED_ROLES; results are the same)
   int group0;            // first 4-row group this launch covers (blockIdx 0); launch_lstm splits a batch into a paired part
                          //   and a remainder
   int f16;               // 1: wfrag holds halves in 4x4x4 fragment order, out (lasth) is written as halves; z stays fp32

@@ -8,7 +8,8 @@
 //   product: M = 4 batch rows, N = 64 columns, K = 1).  Its slice of W_hh lives in VGPRs for the whole sequence
 //   (100 registers per lane; W_hh = 160 KB fp32 = the entire LDS, spread over the waves' register files).
 //   The 4-row MFMA shape is what lets B = 1100 fill the chip: 16-row tiles give 138 workgroups for 256 CUs, 4-row
-//   groups give 550 group-directions; the instruction runs at the same 64 FLOP/clk/SIMD.
+//   groups give 550 group-directions.  The price: a 4x4x1 MFMA occupies the matrix pipe for 10 cycles, not the 8 of its
+//   two passes (tools/ubench/mfma4x4_rate.hip, mfma_valu_overlap.hip): 51 instead of 64 FLOP/clk/SIMD.
 //   (v_mfma_f32_* shares the fp32 VALU datapath -- tools/ubench/barrier_mfma.hip -- so the gate math can
 //   not hide behind it; what counts is total issue time, and this layout needs ONE cell per lane.)
 //
@@ -90,13 +91,14 @@ __device__ __forceinline__ f32x4 gate_transpose(f32x4 v) {
 //     (tools/ubench/mfma4x4_bcast2.hip): 28 MFMAs cover K = 100 instead of 100 MFMAs with 48 of 64 columns multiplying
 //     zeros.  The four partial sums of a column are joined through 1 KB of LDS inside the wave (no extra barrier) in a
 //     fixed order, then the same register transpose and cell update as the heavy waves.
-// NGRP = 2 ("paired", 14 waves = a whole CU): fp32 MFMA and VALU share a SIMD's pipe, so what sets the step time is the
-// fullest SIMD.  Two 7-wave workgroups put 4, 4, 3, 3 waves on the four SIMDs wherever the dispatcher starts them; one
-// 14-wave workgroup's waves go to the SIMDs in cyclic order, so with the two light waves LAST the loads are
-// 3 heavy + light, 3 heavy + light, 3 heavy, 3 heavy: 0.69 ms instead of 0.80 ms per resident round at T = 400.
-// A paired workgroup fills its CU; launch_lstm uses it for as many groups as fit one round (256 CUs x 8 rows = 1024
-// rows) and NGRP = 1 for the rest.  Both forms do the same arithmetic for a row, so a row's result does not depend on
-// where in the batch it sits.
+// NGRP = 2 ("paired", 14 waves = a whole CU, opt-in): fp32 MFMA and VALU share a SIMD's pipe, so what sets the step time is
+// the fullest SIMD.  Two 7-wave workgroups put 4, 4, 3, 3 waves on the four SIMDs; one 14-wave workgroup's waves go to the
+// SIMDs in cyclic order, so with the two light waves LAST the loads are 3 heavy + light, 3 heavy + light, 3 heavy, 3 heavy
+// on every CU.  Measured it buys nothing (0.767 against 0.763 ms per resident round at T = 400): the single barrier now
+// spans both groups and the latency two independent workgroups hide in each other comes back.  NGRP = 1 balances most CUs
+// by choosing its light wave from the SIMD slot ids (below).  launch_lstm uses the paired form, when asked, for as many
+// groups as fit one round (256 CUs x 8 rows = 1024 rows) and NGRP = 1 for the rest.  Both forms do the same arithmetic for
+// a row, so a row's result does not depend on where in the batch it sits.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int REC_HEAVY = 6;                   // heavy waves per group: wave w owns units [16w, 16w + 16)
 constexpr int LIGHT_MF = 28;                   // MFMAs of a light wave per step: q = 0..6 times abid = 0..3
@@ -112,9 +114,30 @@ __global__ __launch_bounds__(64 * LSTM_NW * NGRP, 4) void lstm_kernel(const Lstm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dir = blockIdx.x % p.ndir;
   const int gbase = p.group0 + (blockIdx.x / p.ndir) * NGRP;            // first 4-row group of this workgroup
-  const bool light = wave >= NGRP * REC_HEAVY;
-  const int grp = light ? wave - NGRP * REC_HEAVY : wave / REC_HEAVY;   // group inside the workgroup
-  const int hq = light ? 6 : wave % REC_HEAVY;                           // k-group (tile q of the h buffer) this wave's cells write
+  // Which wave takes the light role.  fp32 MFMA and VALU share a SIMD's pipe, so the step time is set by the fullest
+  // SIMD.  The dispatcher deals a workgroup's waves to the SIMDs cyclically and starts the second 7-wave workgroup of a
+  // CU one SIMD further (tools/ubench/wave_placement.hip: 0213021|2130213), which leaves 4, 4, 3, 3 waves on the four
+  // SIMDs; with the light role fixed to wave 6 one of the two light waves sits on a 3-wave SIMD and the other 4-wave SIMD
+  // carries four heavy waves.  A wave's slot index inside its SIMD (HW_ID.wave_id) says how full that SIMD was when the
+  // wave arrived: the first wave that got slot 3 sits on a full SIMD and takes the light role; without one (first
+  // workgroup on the CU) wave 6 does, which is on the other SIMD that fills up.  Loads become 3 heavy (+ light) on all
+  // four SIMDs.  Roles only say which wave computes which columns: results do not depend on them.
+  int lw = NGRP * REC_HEAVY;
+  if constexpr (NGRP == 1) {
+    __shared__ int simd_slot[LSTM_NW];
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (lane == 0) simd_slot[wave] = (int)(hwid & 15u);
+    __syncthreads();
+#pragma unroll
+    for (int i = LSTM_NW - 1; i >= 0; --i)
+      if (simd_slot[i] == 3 && !p.fixed_roles) lw = i;
+    lw = __builtin_amdgcn_readfirstlane(lw);
+  }
+  const bool light = NGRP == 1 ? wave == lw : wave >= NGRP * REC_HEAVY;
+  const int hwave = (NGRP == 1 && wave > lw) ? wave - 1 : wave;          // heavy waves numbered 0 .. 6 NGRP - 1 in wave order
+  const int grp = light ? (NGRP == 1 ? 0 : wave - NGRP * REC_HEAVY) : hwave / REC_HEAVY;   // group inside the workgroup
+  const int hq = light ? 6 : hwave % REC_HEAVY;                          // k-group (tile q of the h buffer) this wave's cells write
   const int g0 = gbase + grp;                                            // this wave's 4-row group
 
   // ---- recurrent weights of this wave: 100 registers (heavy: its 64 columns for every k) or 28 (light: K-split)

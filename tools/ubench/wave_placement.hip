@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <map>
+#include <string>
 #include <vector>
 __global__ __launch_bounds__(448, 4) void k(unsigned* out, int spin) {
   __shared__ float lds[512];
@@ -59,6 +60,32 @@ int main() {
       ++shown;
     }
   }
+  // histogram of the SIMD sequences (wave 0..6) of the workgroups sharing a CU
+  std::map<std::string, int> pat;
+  for (auto& kv : cus) {
+    std::string key;
+    for (int w : kv.second) {
+      for (int i = 0; i < 7; ++i) key += char('0' + ((h[(w * 7 + i) * 2] >> 4) & 3));
+      key += '|';
+    }
+    ++pat[key];
+  }
+  for (auto& kv : pat) printf("pattern %s : %d CUs\n", kv.first.c_str(), kv.second);
+  // the recurrence's role rule (lstm.hip): light = first wave of the workgroup whose slot is 3, else wave 6
+  std::map<std::string, int> heavy;
+  for (auto& kv : cus) {
+    int hl[4] = {0, 0, 0, 0}, ll[4] = {0, 0, 0, 0};
+    for (int w : kv.second) {
+      int lw = 6;
+      for (int i = 6; i >= 0; --i)
+        if ((h[(w * 7 + i) * 2] & 15) == 3) lw = i;
+      for (int i = 0; i < 7; ++i) ++(i == lw ? ll : hl)[(h[(w * 7 + i) * 2] >> 4) & 3];
+    }
+    char key[64];
+    snprintf(key, sizeof key, "heavy %d %d %d %d light %d %d %d %d", hl[0], hl[1], hl[2], hl[3], ll[0], ll[1], ll[2], ll[3]);
+    ++heavy[key];
+  }
+  for (auto& kv : heavy) printf("roles: %s : %d CUs\n", kv.first.c_str(), kv.second);
   printf("%zu CUs used; CUs by waves on their fullest SIMD:", cus.size());
   for (int i = 0; i < 8; ++i)
     if (hist[i]) printf("  %d waves: %d", i, hist[i]);
