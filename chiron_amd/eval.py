@@ -67,9 +67,28 @@ def slice_ctc_decoding_result(input_decode, start, end):
     return [slice_sparse_tensor(d, start, end) for d in decoded], log_prob[start:end, :]
 
 
+_BASE_CODES = np.frombuffer(BASES.encode("ascii"), dtype=np.uint8)
+
+
 def index2base(read):
-    """chiron_eval.py:100-113."""
-    return "".join(BASES[int(x)] for x in read)
+    """chiron_eval.py:100-113: base indices -> string, as one table lookup (an index outside 0..3 raises IndexError as
+    the reference's per-element lookup does; negative indices count from the end, likewise)."""
+    idx = np.asarray(read)
+    if idx.size == 0:
+        return ""
+    return _BASE_CODES[idx.astype(np.intp, copy=False)].tobytes().decode("ascii")
+
+
+def bases_of_reads(reads):
+    """index2base over a ragged list of reads with one lookup for all of them (a long read has hundreds of windows)."""
+    if len(reads) == 0:
+        return []
+    lengths = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
+    if lengths.sum() == 0:
+        return [""] * len(reads)
+    text = index2base(np.concatenate([np.asarray(r).ravel() for r in reads]))
+    ends = np.cumsum(lengths)
+    return [text[e - n:e] for e, n in zip(ends.tolist(), lengths.tolist())]
 
 
 def get_assembler_kernal(jump, segment_len):
@@ -102,7 +121,10 @@ def qs(consensus, consensus_qs, output_standard="phred+33"):
     if output_standard == "number":
         return score
     if output_standard == "phred+33":
-        return "".join(map(chr, score + 33))
+        codes = score + 33
+        if codes.min() >= 0 and codes.max() < 128:      # every realistic score: one ASCII byte per column
+            return codes.astype(np.uint8).tobytes().decode("ascii")
+        return "".join(map(chr, codes))
     raise ValueError("output_standard must be 'number' or 'phred+33'")
 
 
@@ -133,11 +155,13 @@ class OutputTree(object):
     def segments(self, file_pre, reads, qualities=None):
         """segments/<pre>.<suffix>: a FASTA-style record per window, named <pre><window index>; with per-window quality
         strings (never passed by `chiron call`, chiron_eval.py:460-462) a FASTQ record follows each."""
+        records = []
+        for k, read in enumerate(reads):
+            records.append(">%s%d\n%s\n" % (file_pre, k, read))
+            if self.suffix == "fastq" and qualities is not None:
+                records.append("@%s%d\n%s\n+\n%s\n" % (file_pre, k, read, qualities[k]))
         with open(self._path("segments", file_pre, self.suffix), "w") as f:
-            for k, read in enumerate(reads):
-                f.write(">%s%d\n%s\n" % (file_pre, k, read))
-                if self.suffix == "fastq" and qualities is not None:
-                    f.write("@%s%d\n%s\n+\n%s\n" % (file_pre, k, read, qualities[k]))
+            f.write("".join(records))
 
     def meta(self, file_pre, n_bases, stamps, settings):
         """meta/<pre>.meta: stage durations derived from the cumulative stamps (start, reading, basecall, assembly) and
@@ -291,7 +315,7 @@ def finish_read(name, reads, qs_list, FLAGS, t_start, reading_time):
     """chiron_eval.py:446-462: bases, consensus vote, quality string, writers."""
     file_pre = os.path.splitext(name)[0]
     basecall_time = time.time() - t_start
-    bpreads = [index2base(read) for read in reads]
+    bpreads = bases_of_reads(reads)
     js_ratio = FLAGS.jump / FLAGS.segment_len
     kernal = get_assembler_kernal(FLAGS.jump, FLAGS.segment_len)
     qs_string = None
@@ -338,7 +362,7 @@ def evaluation(FLAGS, engine=None, file_list=None):
     # packs batches and talks to the engine.  Batches are packed in file order, so results do not depend on timing.
     n_threads = max(1, int(getattr(FLAGS, "threads", 0) or 4))
     readers = ThreadPoolExecutor(max_workers=n_threads)
-    finishers = ThreadPoolExecutor(max_workers=max(1, n_threads // 2))
+    finishers = ThreadPoolExecutor(max_workers=n_threads)
     finishing = []
 
     def drain(slot):

@@ -368,7 +368,7 @@ def do_inference(FLAGS, client=None):
         if not reads:
             continue
         probs = np.concatenate(probs)
-        bpreads = [ce.index2base(r) for r in reads]
+        bpreads = ce.bases_of_reads(reads)
         consensus, qs_consensus = assembly.simple_assembly_qs(bpreads, probs, FLAGS.jump / FLAGS.segment_len, kernal=kernal)
         qs_string = ce.qs(consensus, qs_consensus)
         c_bpread = ce.index2base(np.argmax(consensus, axis=0))

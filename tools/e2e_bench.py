@@ -20,6 +20,7 @@ def main():
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     beam = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     prof = len(sys.argv) > 3 and sys.argv[3] == "profile"
+    timeline = len(sys.argv) > 3 and sys.argv[3] == "timeline"
     d = tempfile.mkdtemp(prefix="e2e_")
     inp = os.path.join(d, "in")
     os.makedirs(inp)
@@ -41,6 +42,20 @@ def main():
         ce.evaluation(F, engine=eng)          # warm-up (page cache, first launches)
         shutil.rmtree(F.output)
         pr = cProfile.Profile() if prof else None
+        ev = []
+        if timeline:   # where the wall time goes: engine calls on the main thread, reader waits, finisher spans
+            import threading
+            for obj, name in ((eng, "submit"), (eng, "collect"), (ce, "finish_read"), (ce.signal_io, "read_data_for_eval"),
+                              (ce.assembly, "simple_assembly_qs"), (ce, "qs"), (ce, "write_output"), (ce, "index2base")):
+                fn = getattr(obj, name)
+
+                def wrapped(*a, _fn=fn, _name=name, **k):
+                    t = time.time()
+                    try:
+                        return _fn(*a, **k)
+                    finally:
+                        ev.append((_name, threading.get_ident(), t, time.time()))
+                setattr(obj, name, wrapped)
         t0 = time.time()
         if pr:
             pr.enable()
@@ -53,6 +68,17 @@ def main():
           % (n_reads, windows, beam, dt, windows / dt, windows * 390 / (4000 / 450.0) / 1000 / dt, t_write))
     if pr:
         pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+    if timeline:
+        for name in ("submit", "collect", "finish_read", "read_data_for_eval", "simple_assembly_qs", "qs", "write_output", "index2base"):
+            spans = [(a - t0, b - t0) for n, _, a, b in ev if n == name]
+            tot = sum(b - a for a, b in spans)
+            print("%-20s calls %4d  total %.3f s  mean %.2f ms  first start %.3f  last end %.3f  threads %d"
+                  % (name, len(spans), tot, 1e3 * tot / max(1, len(spans)), min(a for a, _ in spans), max(b for _, b in spans),
+                     len(set(t for n, t, _, _ in ev if n == name))))
+        sub = sorted(a - t0 for n, _, a, b in ev if n == "submit")
+        gaps = np.diff(sub)
+        print("submit-to-submit gap: mean %.2f ms, p50 %.2f, p90 %.2f, max %.2f" % (1e3 * gaps.mean(), 1e3 * np.median(gaps),
+                                                                                  1e3 * np.percentile(gaps, 90), 1e3 * gaps.max()))
     shutil.rmtree(d)
 
 
