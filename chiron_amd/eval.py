@@ -343,7 +343,7 @@ def evaluation(FLAGS, engine=None, file_list=None):
     if own_engine:
         spec, weights, _ = model_mod.load_model(FLAGS.model, allow_synthetic=getattr(FLAGS, "synthetic_weights", False))
         engine = Engine(spec, weights, max_batch=FLAGS.batch_size, segment_len=FLAGS.segment_len,
-                        device_id=getattr(FLAGS, "device", 0), n_slots=2, max_beam=FLAGS.beam,
+                        device_id=getattr(FLAGS, "device", 0), n_slots=int(getattr(FLAGS, "slots", 0) or 3), max_beam=FLAGS.beam,
                         dtype=getattr(FLAGS, "dtype", "fp32"))
     files, file_dir = list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
     if file_list is not None:

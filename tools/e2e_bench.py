@@ -38,7 +38,7 @@ def main():
     F.beam = beam
     spec = ca.dna_default_spec()
     w = ca.synthetic_weights(spec, seed=1234)
-    with ca.Engine(spec, w, max_batch=1100, segment_len=400, n_slots=2, max_beam=beam) as eng:
+    with ca.Engine(spec, w, max_batch=1100, segment_len=400, n_slots=int(os.environ.get("E2E_SLOTS", "3")), max_beam=beam) as eng:
         ce.evaluation(F, engine=eng)          # warm-up (page cache, first launches)
         shutil.rmtree(F.output)
         pr = cProfile.Profile() if prof else None
