@@ -152,6 +152,7 @@ struct LstmPlan {
   ConvGemmPlan proj[2];  // STACK / layer 0: proj[0] covers both directions; MULTI l>0: one per dir
   int nproj = 1;
   float* wfrag = nullptr;
+  void* wwide = nullptr;    // f16: recurrent weights in the 16x16x16 B-operand order of lstm16w_kernel
   float* wlight = nullptr;  // K-split fragment of units 96..99 for the paired recurrence (fp32, H = 100)
 };
 
@@ -213,6 +214,7 @@ struct chiron_engine {
   chiron_engine_opts opts;
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
+  bool lstm16_narrow = false;     // A/B switch: f16 recurrence on 4-row workgroups only
   bool lstm_fixed_roles = false;  // A/B switch: light role always on wave 6
   bool lstm_paired = false;  // fp32 recurrence: 14-wave workgroups for the part of a batch that fits one resident round
   bool bn_batch = false;  // desc.bn_mode == CHIRON_BN_BATCH
@@ -587,6 +589,24 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       _Float16* d16 = nullptr;
       if ((st = dev_upload(e, &d16, wh))) return st;
       lp.wfrag = reinterpret_cast<float*>(d16);
+      if (H == 100) {
+        // lstm16w_kernel: [dir][wave 8][slot 4][k-step 7][lane][4 halves]; lane = kq*16 + 4u + gate, tile = 3 wave + slot
+        std::vector<_Float16> ww((size_t)2 * 8 * 4 * 7 * 64 * 4, (_Float16)0.f);
+        for (int dir = 0; dir < 2; ++dir)
+          for (int wv = 0; wv < 8; ++wv)
+            for (int slot = 0; slot < (wv == 7 ? 4 : 3); ++slot)
+              for (int ks = 0; ks < 7; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                  for (int q = 0; q < 4; ++q) {
+                    const int k = 16 * ks + 4 * (lane >> 4) + q, g = lane & 3, unit = 4 * (3 * wv + slot) + ((lane >> 2) & 3);
+                    if (k < H && unit < H)
+                      ww[(((((size_t)dir * 8 + wv) * 4 + slot) * 7 + ks) * 64 + lane) * 4 + q] =
+                          (_Float16)kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + unit];
+                  }
+        _Float16* dw = nullptr;
+        if ((st = dev_upload(e, &dw, ww))) return st;
+        lp.wwide = dw;
+      }
     } else if ((st = dev_upload(e, &lp.wfrag, wf))) {
       return st;
     }
@@ -768,6 +788,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   // with another slot's GEMM workgroups, gives the higher throughput (3905 vs 4004 kbases/s on one box).
   e->lstm_paired = getenv("CHIRON_LSTM_PAIR") != nullptr;
   e->lstm_fixed_roles = getenv("CHIRON_LSTM_FIXED_ROLES") != nullptr;
+  e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;
   st = build_plans(e, weights);
   if (st == CHIRON_OK) {
     e->slots.resize(e->opts.n_slots);
@@ -1117,6 +1138,8 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.z = s->z;
     r.wfrag = lp.wfrag;
     r.wlight = lp.wlight;
+    r.wwide = lp.wwide;
+    r.narrow16 = e->lstm16_narrow ? 1 : 0;
     r.seq_len = s->seq;
     r.out = e->split ? s->lasth_f32 : outbuf;
     r.T = T;

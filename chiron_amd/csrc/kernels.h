@@ -99,6 +99,8 @@ struct LstmParams {
   const float* wfrag;    // [ndir][LSTM_NW][LSTM_K][64 lanes] recurrent weights, fragment order
   const float* wlight;   // [ndir][28][64 lanes] units 96..99 in the K-split order of the light wave (fp32 kernel):
                          //   entry m = 4q + a, lane = kg*16 + gate*4 + j  ->  W_hh[k = 16q + 4kg + a][gate*H + 96 + j]
+  const void* wwide;     // f16 wide form: [ndir][8 waves][4 tile slots][7 k-steps][64 lanes][4 halves], lane = kq*16 + 4u + gate ->
+                         //   W_hh[k = 16 ks + 4 kq + e][gate*H + 4 tile + u], tile = 3 wave + slot (zero past K or the wave's tiles)
   const int32_t* seq_len;  // [BP] (0 for padded rows)
   float* out;            // lasth [T][BP][ndir*H] time major
   int T, B, BP, H;
@@ -107,6 +109,7 @@ struct LstmParams {
   int fixed_roles;       // fp32: 1 = wave 6 is always the light wave (A/B switch CHIRON_LSTM_FIXED_ROLES; results are the same)
   int group0;            // first 4-row group this launch covers (blockIdx 0); launch_lstm splits a batch into a paired part
                          //   and a remainder
+  int narrow16;          // f16: 1 = 4-row workgroups only (A/B switch CHIRON_LSTM16_NARROW)
   int f16;               // 1: wfrag holds halves in 4x4x4 fragment order, out (lasth) is written as halves; z stays fp32
 };
 void launch_lstm(const LstmParams& p, hipStream_t stream);

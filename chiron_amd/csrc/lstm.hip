@@ -502,17 +502,138 @@ void launch_split_convert(const float* src, void* dst, long rows, int cols, int 
 }
 
 
-void launch_lstm(const LstmParams& p0, hipStream_t stream) {
-  // hidden = 100 is the only size the reference's shipped models use (rnn.py:23 hidden_num=100)
-  LstmParams p = p0;
-  p.group0 = 0;
-  const int groups = p.BP / 4;
-  if (p.f16) {
-    hipLaunchKernelGGL(lstm16_kernel, dim3(groups * p.ndir), dim3(64 * LSTM_NW), 0, stream, p);
-    return;
+// ---------------------------------------------------------------------------------------------------------
+// f16, wide form: one workgroup = SIXTEEN batch rows x one direction on v_mfma_f32_16x16x16_f16 (M = 16 rows, N = 16
+// columns = 4 units x 4 gates, K = 16; 8 cycles, the full f16 rate -- the 4x4x4 form above pays 10 cycles for a
+// sixteenth of the work).  B = 4096 (BASELINE configs[4]) gives 512 workgroups = 2 per CU; what remains is the gate math
+// (one cell per lane and column tile).  8 waves; wave w owns the column tiles 3w .. 3w+2 (wave 7: 21 .. 24) of the 25
+// (H = 100 = 25 x 4 units), their W_hh slices (7 k-steps x 2 registers per tile) resident in VGPRs.
+//   A = h_{t-1} [16 rows][K = 112 padded]: lane (row = lane & 15, kq = lane >> 4) reads h[row][16 s + 4 kq .. +3] for
+//     k-step s -- the LDS tile is laid out [unit tile = 4 s + kq][row][4 units], i.e. lane-linear 8-byte reads, and the
+//     64 cells of a column tile write 128 contiguous bytes;
+//   D: lane (col = lane & 15 = 4 u + gate, q = lane >> 4) holds rows 4q .. 4q+3 of its column: z (stored [col][4 rows] by
+//     the projection, one 8-byte load per lane and tile) is added in place, then a 4 x 4 transpose inside each lane quad
+//     gives lane (u, r) the four gates of cell (row 4q + r, unit 4 tile + u).  The kernel is VALU-bound (gate math of four
+//     cells per lane and step), so the transpose goes through 1.1 KB of wave-private LDS -- one ds_write_b128, two
+//     ds_read2_b32, bank-conflict free with 16 bytes of padding per 16 lanes -- instead of 4 DPP moves + 8 selects per tile.
+//     (The transposed product D = W^T h^T delivers the four gates of a cell to one lane directly, but then z needs four
+//     2-byte loads per lane and tile: measured 1.40 ms against 1.12 ms per launch at B = 4096.)
+// Same cell arithmetic as lstm16_kernel; the k order of the fp32 accumulation differs (16 per MFMA instead of 4), so
+// the two forms agree to rounding, not bit for bit; which one runs depends only on the padded batch size.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int W16_NW = 8;       // waves per workgroup
+constexpr int W16_NT = 4;       // column-tile slots per wave (3 used by waves 0..6)
+constexpr int W16_KS = 7;       // k-steps of 16: K = 100 padded to 112
+constexpr int HW16 = 28 * 64;   // halves per h buffer: 28 unit tiles x 16 rows x 4 units (tiles 25..27 stay zero)
+
+constexpr int W16_XF = 288;     // floats of transpose scratch per wave and tile slot (64 x 4 + 4 per 16 lanes of padding)
+
+__global__ __launch_bounds__(64 * W16_NW, 2) void lstm16w_kernel(const LstmParams p) {
+  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * HW16];
+  __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * W16_XF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x % p.ndir;
+  const int g16 = blockIdx.x / p.ndir;                 // 16-row group = the 4-row groups 4 g16 .. 4 g16 + 3
+  const int nt = wave == W16_NW - 1 ? 4 : 3;           // column tiles of this wave
+  const int tile0 = 3 * wave;
+
+  f16x4 w[W16_NT][W16_KS];
+  {
+    const f16x4* wf = reinterpret_cast<const f16x4*>(p.wwide) + ((long)dir * W16_NW + wave) * W16_NT * W16_KS * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+#pragma unroll
+      for (int ks = 0; ks < W16_KS; ++ks) w[n][ks] = wf[(n * W16_KS + ks) * 64];
   }
-  // Paired workgroups (one per CU) for as many groups as fit ONE resident round, 7-wave workgroups for the rest: a
-  // paired workgroup fills its CU, so a second round of them would cost a whole round however few there are.
+  for (int i = tid; i < 2 * HW16; i += 64 * W16_NW) hbuf[i] = (_Float16)0.f;
+
+  const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;   // before the transpose: column 4u + gp, rows 4q .. 4q+3
+  const int row = 4 * q + gp;                                      // after it: this lane's cell is (row, unit 4 tile + u)
+  const int brow = g16 * 16 + row;
+  const int lenr = min(p.seq_len[brow], p.T);
+  int maxlen = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) maxlen = max(maxlen, min(p.seq_len[g16 * 16 + r], p.T));
+  __syncthreads();
+
+  const unsigned outw = p.ndir * p.H;
+  const unsigned zcols = 4 * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;        // halves between consecutive steps
+  // byte offset of this lane's 4 halves (rows 4q..4q+3 of column gate*H + unit) for tile slot 0; + 32 bytes per tile
+  const unsigned zlane_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 4 * tile0 + u) * 4) * 2;
+  const unsigned ostep = p.BP * outw;
+  const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;  // + 4 per tile
+  const int hw = tile0 * 64 + row * 4 + u;                          // + 64 per tile
+  _Float16* outh = reinterpret_cast<_Float16*>(p.out);
+
+  // transpose scratch: lane l = (q, u, gp) stores its 4 rows at float 4 l + 4 q; lane (q, u, r) then reads gate g at
+  // float 4 (16 q + 4 u + g) + 4 q + r: bank 16 u + 4 g + 4 q + r, distinct over the wave for every g
+  float* const xw = xf + wave * W16_NT * W16_XF + 4 * lane + 4 * q;
+  const float* const xr = xf + wave * W16_NT * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+
+  float c[W16_NT] = {0.f, 0.f, 0.f, 0.f}, hprev[W16_NT] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (int s = 0; s < maxlen; ++s) {
+    const _Float16* zs = reinterpret_cast<const _Float16*>(p.z) + (size_t)s * zstep;   // wave-uniform
+    f16x4 zh[W16_NT];
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(zh[0]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:32" : "=v"(zh[1]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:64" : "=v"(zh[2]) : "v"(zlane_b), "s"(zs) : "memory");
+    if (nt == 4) asm volatile("global_load_dwordx2 %0, %1, %2 offset:96" : "=v"(zh[3]) : "v"(zlane_b), "s"(zs) : "memory");
+    else zh[3] = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    const f16x4* hb = reinterpret_cast<const f16x4*>(hbuf + cur * HW16) + lane;
+    f16x4 hv[W16_KS];
+#pragma unroll
+    for (int ks = 0; ks < W16_KS; ++ks) hv[ks] = hb[ks * 64];
+    f32x4 acc[W16_NT];
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n < nt) {
+#pragma unroll
+        for (int ks = 0; ks < W16_KS; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(hv[ks], w[n][ks], acc[n], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh[0]), "+v"(zh[1]), "+v"(zh[2]), "+v"(zh[3]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    const bool act = s < lenr;
+    const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      if (n < nt) {
+        *reinterpret_cast<f32x4*>(xw + n * W16_XF) = acc[n] + (f32x4){(float)zh[n][0], (float)zh[n][1], (float)zh[n][2], (float)zh[n][3]};
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // wave-private scratch: LDS operations of a wave execute in order
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      if (n < nt) {
+        const float* xs = xr + n * W16_XF;
+        const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};   // i, j, f, o of (row, unit 4 (tile0 + n) + u)
+        float hnew;
+        const float cn = lstm_cell(gates, c[n], &hnew);
+        c[n] = act ? cn : c[n];
+        hprev[n] = act ? hnew : hprev[n];
+        hbuf[(cur ^ 1) * HW16 + hw + 64 * n] = (_Float16)hprev[n];
+        outh[to * ostep + olane + 4 * n] = (_Float16)(act ? hnew : 0.f);
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+
+  // ---- frames past the longest row of the workgroup read back as zeros (dynamic_rnn semantics)
+  for (int s = maxlen; s < p.T; ++s)
+    for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
+      const int r = i / p.H;
+      const int uu = i - r * p.H;
+      outh[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
+    }
+}
+
+static int lstm_cu_count() {
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -520,6 +641,26 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
+  return n_cu;
+}
+
+void launch_lstm(const LstmParams& p0, hipStream_t stream) {
+  // hidden = 100 is the only size the reference's shipped models use (rnn.py:23 hidden_num=100)
+  LstmParams p = p0;
+  p.group0 = 0;
+  const int groups = p.BP / 4;
+  if (p.f16) {
+    // sixteen-row workgroups for whole 16-row groups, 4-row workgroups for what is left of the padded batch
+    // (138 wide workgroups of B = 1100 leave half the CUs idle: 0.68 ms against 0.53 ms for 550 narrow ones)
+    const int wide = (p.wwide && !p.narrow16 && (p.BP / 16) * p.ndir >= lstm_cu_count()) ? p.BP / 16 : 0;
+    if (wide > 0) hipLaunchKernelGGL(lstm16w_kernel, dim3(wide * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    p.group0 = 4 * wide;
+    if (groups > p.group0) hipLaunchKernelGGL(lstm16_kernel, dim3((groups - p.group0) * p.ndir), dim3(64 * LSTM_NW), 0, stream, p);
+    return;
+  }
+  // Paired workgroups (one per CU) for as many groups as fit ONE resident round, 7-wave workgroups for the rest: a
+  // paired workgroup fills its CU, so a second round of them would cost a whole round however few there are.
+  const int n_cu = lstm_cu_count();
   const int pairs = p.paired ? std::min(groups / 2, n_cu / p.ndir) : 0;
   if (pairs > 0) hipLaunchKernelGGL(lstm_kernel<2>, dim3(pairs * p.ndir), dim3(64 * LSTM_NW * 2), 0, stream, p);
   p.group0 = 2 * pairs;
