@@ -732,6 +732,41 @@ def _levenshtein(a, b):
     return prev[-1]
 
 
+def test_f16_wide_and_narrow_recurrence_forms_agree(dna, monkeypatch):
+    """lstm.hip lstm16w_kernel (16-row workgroups on the 16x16x16 f16 MFMA, taken when they fill the CUs) against
+    lstm16_kernel (4-row workgroups, CHIRON_LSTM16_NARROW=1) on one batch: 4108 rows = 256 wide workgroups per direction plus
+    three narrow groups for the rest, with zero-length, one-frame and ragged rows at the start, in the middle and in the
+    narrow remainder.  Both accumulate the same f16 products in fp32 in a different k order, so logits agree to fp32
+    rounding carried through three layers (measured ~1e-3; bound 1e-2, well under the fp16-vs-fp32 tolerance of 0.08),
+    frames past a row's length are exactly zero-fed in both, and the greedy strings are the same for most rows (measured
+    99.3 %: h is rounded to f16 every step, so a last-bit difference in the sum can flip that rounding; the fp16 engine
+    against the fp32 one is at 95-97 %; bound 98 %)."""
+    spec, w = dna
+    L, B = 400, 4108
+    x, ln = _windows(390 * (B - 1) + 91, L, 390, seed=47)
+    ln = ln.copy()
+    ln[[0, 5, 17, 2049, 4095, 4096, 4101, 4107]] = [0, 1, 250, 3, 399, 0, 120, 7]
+    out = []
+    for narrow in (False, True):
+        if narrow:
+            monkeypatch.setenv("CHIRON_LSTM16_NARROW", "1")
+        else:
+            monkeypatch.delenv("CHIRON_LSTM16_NARROW", raising=False)
+        with ca.Engine(spec, w, max_batch=B, segment_len=L, dtype="fp16") as eng:
+            sl = ca.seq_len_for_engine(ln, eng.ratio)
+            out.append(eng.infer(x, sl, want_logits=True))
+    monkeypatch.delenv("CHIRON_LSTM16_NARROW", raising=False)
+    T = out[0].logits.shape[1]
+    mask = np.arange(T)[None, :] < sl[:, None]
+    d = np.abs(out[0].logits - out[1].logits)
+    assert d[mask].max() < 1e-2, d[mask].max()
+    # past a row's length the recurrence emits zeros in both forms: the logits there are the FC bias path, identical
+    assert np.array_equal(out[0].logits[~mask].view(np.uint32), out[1].logits[~mask].view(np.uint32))
+    a, b = _beam_rows(out[0], B), _beam_rows(out[1], B)
+    same = np.mean([p == q for p, q in zip(a, b)])
+    assert same > 0.98, same
+
+
 def test_f16_config5_full_batch_edit_distance_distribution(dna):
     """BASELINE configs[4] at its real size: DNA_default, fp16 conv + LSTM / fp32 CTC, batch 4096, against the fp32 engine
     on the same 4096 windows.  Reported, not tuned to pass: the distribution of the per-window edit distance between the
