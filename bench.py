@@ -235,6 +235,15 @@ def main():
                     "lstm_gemm_flop_per_window": LSTM_GEMM_FLOP_PER_WINDOW,
                     "mfma_kernels": per_bucket,
                     "traffic_source": traffic_src}
+        # north_star: "rocprof HBM GB/s on the conv and MFMA utilisation on the LSTM": the PMC pass's counters next to this
+        # run's launch times (HBM GB/s = PMC bytes per launch / HIP-event launch time); absent when the PMC record is stale
+        for k in mfma_buckets:
+            pc = pmc_counters(BUCKET_SYMBOL[k])
+            if pc is not None:
+                per_bucket[k]["pmc"] = pc
+                if pc["hbm_bytes_per_launch"]:
+                    per_bucket[k]["hbm_gbps_pmc"] = round(pc["hbm_bytes_per_launch"] / (stats[k]["total_ms"] / stats[k]["launches"] * 1e-3) / 1e9, 1)
+        roofline["pmc"] = pmc_counters(dom_symbol)
         fam = [s for k, s in stats.items() if k.startswith("conv_") or k.startswith("lstm_proj")]
         gemm_family = {"launches_per_batch": sum(s["launches"] for s in fam) / 3.0,
                        "tflops": round(sum(s["flops"] for s in fam) / (sum(s["total_ms"] for s in fam) * 1e-3) / 1e12, 2),
@@ -371,7 +380,22 @@ def pmc_traffic(kernel):
         sys.stderr.write("bench.py: %s was collected on kernel sources %s, the tree holds %s: roofline.traffic withheld; "
                          "re-run tools/pmc_pass.sh + tools/pmc_to_json.py\n" % (name, have, want))
         return None, "STALE: %s was collected on kernel sources %s, this tree is %s" % (name, have, want)
+    _PMC_DOC.update(doc)
     return doc.get(kernel, {}).get("hbm_bytes"), "static %s @ kernel sources %s (separate --pmc pass, not this run)" % (name, want)
+
+
+_PMC_DOC = {}   # the PMC record pmc_traffic() accepted (same kernel sources as this tree), else empty
+
+
+def pmc_counters(kernel):
+    """MFMA-busy fraction, LDS bank-conflict fraction, L2 hit rate and HBM bytes per launch of `kernel` from the accepted PMC
+    record, or None."""
+    rec = _PMC_DOC.get(kernel)
+    if not isinstance(rec, dict):
+        return None
+    return {"mfma_busy_frac": round(rec.get("mfma_busy_frac_of_all_simds", 0.0), 4),
+            "lds_bank_conflict_frac": round(rec.get("lds_bank_conflict_frac", 0.0), 4),
+            "l2_hit_rate": round(rec.get("l2_hit_rate", 0.0), 4), "hbm_bytes_per_launch": rec.get("hbm_bytes")}
 
 
 def cpu_baseline(spec, weights, xb, lb, ratio, n_windows):

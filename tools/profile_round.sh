@@ -1,0 +1,46 @@
+#!/bin/bash
+# Everything under profiles/rNN_* in one gpurun call (run from the repo root on the GPU box):
+#   tools/profile_round.sh r02        ->  gpurun_out/r02/...   (copy what is to be judged into profiles/ afterwards)
+# Order matters: the PMC record is written into profiles/ on the box BEFORE the bench runs, so that bench.py finds a record
+# collected on this tree's kernel sources (roofline.traffic / roofline.pmc are withheld otherwise).
+set -u
+R=${1:-r02}
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/$R
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+
+# 1. PMC passes (separate runs per counter group, --kernel-trace only) -> json + text summary
+bash tools/pmc_pass.sh "$OUT/pmc" > "$OUT/pmc_pass.log" 2>&1
+python tools/pmc_to_json.py "$OUT/pmc" "$OUT/${R}_pmc.json" > /dev/null 2> "$OUT/pmc_json.err"
+python tools/pmc_summary.py "$OUT/pmc" > "$OUT/${R}_pmc_summary.txt" 2>> "$OUT/pmc_json.err"
+cp "$OUT/${R}_pmc.json" "profiles/${R}_pmc.json"
+
+# 2. kernel trace of the bench command with one batch in flight (the per-kernel table) + its bench line
+#    (--no-f16: the fp16 / split side runs of the default command would put their kernels into the same trace)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o slots1 -- \
+  python bench.py --slots 1 --steps 5 --rounds 1 --warmup 2 --no-f16 > "$OUT/bench_slots1.json" 2> "$OUT/bench_slots1.err"
+cp "$OUT"/prof/slots1_kernel_stats.csv "$OUT/${R}_kernel_stats_slots1.csv" 2>/dev/null || \
+  find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_kernel_stats_slots1.csv" \;
+
+# 3. the default bench command, three times
+for i in 1 2 3; do python bench.py > "$OUT/bench_default_$i.json" 2> "$OUT/bench_default_$i.err"; done
+cp "$OUT/bench_default_1.json" "$OUT/bench_default.json"
+
+# 4. secondary configurations (configs[2], beam widths, configs[4] fp16, split dtype)
+python tools/bench_configs.py > "$OUT/secondary.jsonl" 2> "$OUT/secondary.err"
+python tools/bench_configs.py f16 >> "$OUT/secondary.jsonl" 2>> "$OUT/secondary.err"
+python tools/bench_configs.py split >> "$OUT/secondary.jsonl" 2>> "$OUT/secondary.err"
+
+# 5. end to end through the host pipeline (512 synthetic reads x 100k samples, .signal files -> FASTQ tree)
+python tools/e2e_bench.py 512 0 > "$OUT/e2e.txt" 2> "$OUT/e2e.err"
+python tools/e2e_bench.py 512 30 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+
+# 6. fp16 engine at configs[4], kernel trace
+bash tools/f16_profile.sh > "$OUT/f16_kernels.txt" 2> "$OUT/f16_kernels.err"
+
+for i in 1 2 3; do python -c "
+import json,sys
+j=json.loads(open('$OUT/bench_default_$i.json').read().strip().splitlines()[-1]); r=j['roofline']
+print('default run $i:', j['value'], j['ms_per_step'], r['kernel'], r['frac'], r['traffic'])"; done
+cat "$OUT/e2e.txt"
