@@ -153,6 +153,8 @@ struct LstmPlan {
   int nproj = 1;
   float* wfrag = nullptr;
   void* wwide = nullptr;    // f16: recurrent weights in the 16x16x16 B-operand order of lstm16w_kernel
+  void* wxwide = nullptr;   // f16: input weights in the same order (lstm16f_kernel: projection fused into the recurrence)
+  int wx_ksteps = 0;        //      its k-steps of 16 (16: K = 256, 13: K = 200)
   float* wlight = nullptr;  // K-split fragment of units 96..99 for the paired recurrence (fp32, H = 100)
 };
 
@@ -214,6 +216,7 @@ struct chiron_engine {
   chiron_engine_opts opts;
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
+  bool lstm16_fused = false;      // f16: x-projection inside the recurrence (whole 16-row groups that fill the CUs)
   bool lstm16_narrow = false;     // A/B switch: f16 recurrence on 4-row workgroups only
   bool lstm_fixed_roles = false;  // A/B switch: light role always on wave 6
   bool lstm_paired = false;  // fp32 recurrence: 14-wave workgroups for the part of a batch that fits one resident round
@@ -606,6 +609,26 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
         _Float16* dw = nullptr;
         if ((st = dev_upload(e, &dw, ww))) return st;
         lp.wwide = dw;
+        if (lp.nproj == 1 && (lp.in_w == 256 || lp.in_w == 200)) {
+          // W_x in the same order, k-steps of 16 over the layer's input width (zero past it)
+          const int ksx = lp.in_w == 256 ? 16 : 13;
+          std::vector<_Float16> wxv((size_t)2 * 8 * 4 * ksx * 64 * 4, (_Float16)0.f);
+          for (int dir = 0; dir < 2; ++dir)
+            for (int wv = 0; wv < 8; ++wv)
+              for (int slot = 0; slot < (wv == 7 ? 4 : 3); ++slot)
+                for (int ks = 0; ks < ksx; ++ks)
+                  for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                      const int k = 16 * ks + 4 * (lane >> 4) + q, g = lane & 3, unit = 4 * (3 * wv + slot) + ((lane >> 2) & 3);
+                      if (k < lp.in_w && unit < H)
+                        wxv[(((((size_t)dir * 8 + wv) * 4 + slot) * ksx + ks) * 64 + lane) * 4 + q] =
+                            (_Float16)kern[dir][(size_t)k * 4 * H + g * H + unit];
+                    }
+          _Float16* dx = nullptr;
+          if ((st = dev_upload(e, &dx, wxv))) return st;
+          lp.wxwide = dx;
+          lp.wx_ksteps = ksx;
+        }
       }
     } else if ((st = dev_upload(e, &lp.wfrag, wf))) {
       return st;
@@ -789,6 +812,14 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->lstm_paired = getenv("CHIRON_LSTM_PAIR") != nullptr;
   e->lstm_fixed_roles = getenv("CHIRON_LSTM_FIXED_ROLES") != nullptr;
   e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;
+  {
+    // f16 engines whose padded batch gives every CU a 16-row workgroup per direction (configs[4]: 4096 -> 512) run the
+    // x-projection inside the recurrence (lstm16f_kernel); CHIRON_LSTM16_UNFUSED=1 keeps the projection GEMM + z (A/B switch)
+    hipDeviceProp_t prop;
+    int n_cu = 256;
+    if (hipGetDeviceProperties(&prop, e->opts.device_id) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    e->lstm16_fused = e->f16 && !e->lstm16_narrow && desc->hidden == 100 && (e->BP / 16) * 2 >= n_cu && getenv("CHIRON_LSTM16_UNFUSED") == nullptr;
+  }
   st = build_plans(e, weights);
   if (st == CHIRON_OK) {
     e->slots.resize(e->opts.n_slots);
@@ -1108,7 +1139,9 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
   for (size_t l = 0; l < e->lstm.size(); ++l) {
     const LstmPlan& lp = e->lstm[l];
     float* outbuf = s->lasth[l & 1];
-    for (int pj = 0; pj < lp.nproj; ++pj) {
+    // f16, whole 16-row groups filling the CUs: the projection runs inside the recurrence (lstm16f_kernel), no z
+    const bool fused = e->lstm16_fused && lp.wxwide != nullptr;
+    for (int pj = 0; pj < (fused ? 0 : lp.nproj); ++pj) {
       GemmParams g;
       init_gemm(&g, e, lp.proj[pj], B);
       g.M = T * BP;
@@ -1140,6 +1173,18 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.wlight = lp.wlight;
     r.wwide = lp.wwide;
     r.narrow16 = e->lstm16_narrow ? 1 : 0;
+    r.xsrc = nullptr;
+    r.wxwide = nullptr;
+    r.xbias = nullptr;
+    r.xK = r.xld = r.x_time_major = 0;
+    if (fused) {
+      r.xsrc = l == 0 ? (const void*)fea : (const void*)prev;
+      r.wxwide = lp.wxwide;
+      r.xbias = lp.proj[0].shift;
+      r.xK = lp.in_w;
+      r.xld = l == 0 ? e->C : e->lasth_ld;
+      r.x_time_major = l == 0 ? 0 : 1;
+    }
     r.seq_len = s->seq;
     r.out = e->split ? s->lasth_f32 : outbuf;
     r.T = T;
@@ -1152,7 +1197,8 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.group0 = 0;
     r.f16 = e->f16 ? 1 : 0;
     {
-      Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H, 4.0 * B * T * 2.0 * (zc + H));
+      Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H + (fused ? 2.0 * B * T * (double)lp.in_w * 4 * H * 2.0 : 0.0),
+              fused ? (e->f16 ? 2.0 : 4.0) * B * T * (2.0 * lp.in_w + 2.0 * H) : 4.0 * B * T * 2.0 * (zc + H));
       launch_lstm(r, s->stream);
     }
     prev = outbuf;

@@ -101,6 +101,11 @@ struct LstmParams {
                          //   entry m = 4q + a, lane = kg*16 + gate*4 + j  ->  W_hh[k = 16q + 4kg + a][gate*H + 96 + j]
   const void* wwide;     // f16 wide form: [ndir][8 waves][4 tile slots][7 k-steps][64 lanes][4 halves], lane = kq*16 + 4u + gate ->
                          //   W_hh[k = 16 ks + 4 kq + e][gate*H + 4 tile + u], tile = 3 wave + slot (zero past K or the wave's tiles)
+  // f16, fused with the x-projection (lstm16f_kernel; xsrc == nullptr: z comes from the projection GEMM as above)
+  const void* xsrc;      // layer input, halves: [B][T][xld] (x_time_major 0: CNN features) or [T][BP][xld] (1: previous lasth)
+  const void* wxwide;    // [ndir][8 waves][4 tile slots][KSX k-steps][64 lanes][4 halves]: W_x in the order of wwide, KSX = 16 (K = 256) or 13
+  const float* xbias;    // [ndir][4H] bias + forget bias, column = gate*H + unit (the projection GEMM's shift vector)
+  int xK, xld, x_time_major;
   const int32_t* seq_len;  // [BP] (0 for padded rows)
   float* out;            // lasth [T][BP][ndir*H] time major
   int T, B, BP, H;

@@ -633,6 +633,158 @@ __global__ __launch_bounds__(64 * W16_NW, 2) void lstm16w_kernel(const LstmParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// f16, wide AND fused with the x-projection: the same 16-row workgroups as lstm16w_kernel, but z is never materialised.
+// At B = 4096 the projection GEMM writes 2.6 GB of z per layer and the recurrence reads it back -- 5.2 GB of HBM traffic and
+// a 1.25 ms launch per layer for a product the recurrence's idle matrix pipe can do itself: per step the workgroup gathers
+// its 16 input rows x_t (8 KB; the backward direction walks t = seq_len - 1 - s per row, so this is a per-row gather, not a
+// tile of a GEMM), and every wave multiplies them by ITS columns of W_x, resident in registers next to W_hh (KSX k-steps of
+// 16 x 2 registers per column tile; wave 7 with four tiles holds 184 weight registers: one workgroup per CU, 8 waves).
+//   x tile in LDS: [k quad][row][4 halves], the A-operand order of h (lane-linear 8-byte reads); thread (row = tid / 32,
+//   j = tid % 32) fetches the 16 bytes k = 8j .. 8j+7 of its row one step ahead and stores them as two quads.
+//   K = 200 (layers 1, 2) is padded to 208: the 26th piece of a row is never written and stays zero.
+// ---------------------------------------------------------------------------------------------------------
+template <int KSX>
+__global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParams p) {
+  constexpr int XQ = KSX * 4;                       // k quads of the x tile
+  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * HW16];
+  __shared__ __attribute__((aligned(16))) _Float16 xbuf[2 * XQ * 64];
+  __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * W16_XF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x % p.ndir;
+  const int g16 = blockIdx.x / p.ndir;
+  const int nt = wave == W16_NW - 1 ? 4 : 3;
+  const int tile0 = 3 * wave;
+
+  f16x4 wh[W16_NT][W16_KS], wx[W16_NT][KSX];
+  {
+    const f16x4* wf = reinterpret_cast<const f16x4*>(p.wwide) + ((long)dir * W16_NW + wave) * W16_NT * W16_KS * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+#pragma unroll
+      for (int ks = 0; ks < W16_KS; ++ks) wh[n][ks] = wf[(n * W16_KS + ks) * 64];
+    const f16x4* xwf = reinterpret_cast<const f16x4*>(p.wxwide) + ((long)dir * W16_NW + wave) * W16_NT * KSX * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) wx[n][ks] = xwf[(n * KSX + ks) * 64];
+  }
+  for (int i = tid; i < 2 * HW16; i += 64 * W16_NW) hbuf[i] = (_Float16)0.f;
+  for (int i = tid; i < 2 * XQ * 64; i += 64 * W16_NW) xbuf[i] = (_Float16)0.f;
+
+  const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;
+  const int row = 4 * q + gp;
+  const int brow = g16 * 16 + row;
+  const int lenr = min(p.seq_len[brow], p.T);
+  int maxlen = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) maxlen = max(maxlen, min(p.seq_len[g16 * 16 + r], p.T));
+
+  // bias (+ forget bias) of this lane's column of each tile: the C operand the tile's first MFMA starts from
+  float bias[W16_NT];
+#pragma unroll
+  for (int n = 0; n < W16_NT; ++n) bias[n] = n < nt ? p.xbias[dir * 4 * p.H + gp * p.H + 4 * (tile0 + n) + u] : 0.f;
+
+  // ---- x loader: this thread's piece of the tile
+  const int xr = tid >> 5, xj = tid & 31;
+  const bool xlive = 8 * xj < p.xK;
+  const int xb = g16 * 16 + xr;
+  const int xlen = min(p.seq_len[xb], p.T);
+  const char* const xsrc = reinterpret_cast<const char*>(p.xsrc);
+  auto x_offset = [&](int s) -> unsigned {   // byte offset of the piece for step s (any valid frame for a finished row)
+    int t = dir == 0 ? s : xlen - 1 - s;
+    t = min(max(t, 0), p.T - 1);
+    // rows past the submitted batch have length 0 and are never consumed; they read row B - 1 (the feature tensor holds B rows)
+    const unsigned r = p.x_time_major ? (unsigned)t * p.BP + xb : (unsigned)min(xb, p.B - 1) * p.T + t;
+    return (r * p.xld + 8 * xj) * 2u;
+  };
+  const int xw0 = ((2 * xj) * 16 + xr) * 4;          // halves: quad 2j; quad 2j+1 is 64 halves further
+  __syncthreads();   // the zero fill above is complete before the first pieces land
+  if (xlive && maxlen > 0) {
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xsrc + x_offset(0));
+    *reinterpret_cast<f32x2*>(xbuf + xw0) = (f32x2){x0[0], x0[1]};
+    *reinterpret_cast<f32x2*>(xbuf + xw0 + 64) = (f32x2){x0[2], x0[3]};
+  }
+  __syncthreads();
+
+  const unsigned outw = p.ndir * p.H;
+  const unsigned ostep = p.BP * outw;
+  const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;
+  const int hw = tile0 * 64 + row * 4 + u;
+  _Float16* outh = reinterpret_cast<_Float16*>(p.out);
+  float* const xw = xf + wave * W16_NT * W16_XF + 4 * lane + 4 * q;
+  const float* const xrd = xf + wave * W16_NT * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+
+  float c[W16_NT] = {0.f, 0.f, 0.f, 0.f}, hprev[W16_NT] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (int s = 0; s < maxlen; ++s) {
+    // next step's piece, in flight during this step's arithmetic.  Issued by every lane on every step (lanes past K and the
+    // last step fetch a valid address and drop the data): the register must have the asm as its only definition, a merge
+    // with an older value would let the compiler copy it before the load has landed.
+    f32x4 xpre;
+    {
+      const char* src = xsrc + (xlive ? x_offset(s + 1) : x_offset(0) - 16u * xj);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xpre) : "v"(src) : "memory");
+    }
+    const f16x4* hb = reinterpret_cast<const f16x4*>(hbuf + cur * HW16) + lane;
+    const f16x4* xbp = reinterpret_cast<const f16x4*>(xbuf + cur * XQ * 64) + lane;
+    f32x4 acc[W16_NT];
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) acc[n] = (f32x4){bias[n], bias[n], bias[n], bias[n]};
+#pragma unroll
+    for (int ks = 0; ks < KSX; ++ks) {
+      const f16x4 xa = xbp[ks * 64];
+#pragma unroll
+      for (int n = 0; n < W16_NT; ++n)
+        if (n < nt) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(xa, wx[n][ks], acc[n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < W16_KS; ++ks) {
+      const f16x4 ha = hb[ks * 64];
+#pragma unroll
+      for (int n = 0; n < W16_NT; ++n)
+        if (n < nt) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, wh[n][ks], acc[n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+      if (n < nt) *reinterpret_cast<f32x4*>(xw + n * W16_XF) = acc[n];
+    __builtin_amdgcn_wave_barrier();
+    const bool act = s < lenr;
+    const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      if (n < nt) {
+        const float* xs = xrd + n * W16_XF;
+        const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};
+        float hnew;
+        const float cn = lstm_cell(gates, c[n], &hnew);
+        c[n] = act ? cn : c[n];
+        hprev[n] = act ? hnew : hprev[n];
+        hbuf[(cur ^ 1) * HW16 + hw + 64 * n] = (_Float16)hprev[n];
+        outh[to * ostep + olane + 4 * n] = (_Float16)(act ? hnew : 0.f);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre) : : "memory");
+    if (xlive && s + 1 < maxlen) {
+      _Float16* xd = xbuf + (cur ^ 1) * XQ * 64 + xw0;
+      *reinterpret_cast<f32x2*>(xd) = (f32x2){xpre[0], xpre[1]};
+      *reinterpret_cast<f32x2*>(xd + 64) = (f32x2){xpre[2], xpre[3]};
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+
+  for (int s = maxlen; s < p.T; ++s)
+    for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
+      const int r = i / p.H;
+      const int uu = i - r * p.H;
+      outh[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
+    }
+}
+
 static int lstm_cu_count() {
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -649,6 +801,13 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
   LstmParams p = p0;
   p.group0 = 0;
   const int groups = p.BP / 4;
+  if (p.f16 && p.xsrc) {   // fused with the x-projection: the engine asks for it only when whole 16-row groups cover the batch
+    if (p.xK > 208)
+      hipLaunchKernelGGL(lstm16f_kernel<16>, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    else
+      hipLaunchKernelGGL(lstm16f_kernel<13>, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    return;
+  }
   if (p.f16) {
     // sixteen-row workgroups for whole 16-row groups, 4-row workgroups for what is left of the padded batch
     // (138 wide workgroups of B = 1100 leave half the CUs idle: 0.68 ms against 0.53 ms for 550 narrow ones)
