@@ -153,7 +153,8 @@ struct LstmPlan {
   int nproj = 1;
   float* wfrag = nullptr;
   void* wwide = nullptr;    // f16: recurrent weights in the 16x16x16 B-operand order of lstm16w_kernel
-  void* wxwide = nullptr;   // f16: input weights in the same order (lstm16f_kernel: projection fused into the recurrence)
+  void* whfused = nullptr;  // f16: W_hh in the 16x16x32 order of lstm16f_kernel
+  void* wxwide = nullptr;   // f16: input weights in that order (lstm16f_kernel: projection fused into the recurrence)
   int wx_ksteps = 0;        //      its k-steps of 16 (16: K = 256, 13: K = 200)
   float* wlight = nullptr;  // K-split fragment of units 96..99 for the paired recurrence (fp32, H = 100)
 };
@@ -216,6 +217,7 @@ struct chiron_engine {
   chiron_engine_opts opts;
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
+  bool lstm16_pair = false;       // f16 fused recurrence: two 16-row groups per workgroup (A/B switch)
   bool lstm16_fused = false;      // f16: x-projection inside the recurrence (whole 16-row groups that fill the CUs)
   bool lstm16_narrow = false;     // A/B switch: f16 recurrence on 4-row workgroups only
   bool lstm_fixed_roles = false;  // A/B switch: light role always on wave 6
@@ -610,23 +612,29 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
         if ((st = dev_upload(e, &dw, ww))) return st;
         lp.wwide = dw;
         if (lp.nproj == 1 && (lp.in_w == 256 || lp.in_w == 200)) {
-          // W_x in the same order, k-steps of 16 over the layer's input width (zero past it)
-          const int ksx = lp.in_w == 256 ? 16 : 13;
-          std::vector<_Float16> wxv((size_t)2 * 8 * 4 * ksx * 64 * 4, (_Float16)0.f);
-          for (int dir = 0; dir < 2; ++dir)
-            for (int wv = 0; wv < 8; ++wv)
-              for (int slot = 0; slot < (wv == 7 ? 4 : 3); ++slot)
-                for (int ks = 0; ks < ksx; ++ks)
-                  for (int lane = 0; lane < 64; ++lane)
-                    for (int q = 0; q < 4; ++q) {
-                      const int k = 16 * ks + 4 * (lane >> 4) + q, g = lane & 3, unit = 4 * (3 * wv + slot) + ((lane >> 2) & 3);
-                      if (k < lp.in_w && unit < H)
-                        wxv[(((((size_t)dir * 8 + wv) * 4 + slot) * ksx + ks) * 64 + lane) * 4 + q] =
-                            (_Float16)kern[dir][(size_t)k * 4 * H + g * H + unit];
-                    }
-          _Float16* dx = nullptr;
-          if ((st = dev_upload(e, &dx, wxv))) return st;
+          // lstm16f_kernel (v_mfma_f32_16x16x32_f16): W_x and W_hh as [dir][wave][slot][k-step of 32][lane][8 halves],
+          // lane = kg*16 + 4u + gate -> k = 32 ks + 8 kg + e, column gate*H + 4 (3 wave + slot) + u; zero past the width
+          const int ksx = lp.in_w == 256 ? 8 : 7;
+          auto frag = [&](int ksteps, int k_off, int width) {
+            std::vector<_Float16> v((size_t)2 * 8 * 4 * ksteps * 64 * 8, (_Float16)0.f);
+            for (int dir = 0; dir < 2; ++dir)
+              for (int wv = 0; wv < 8; ++wv)
+                for (int slot = 0; slot < (wv == 7 ? 4 : 3); ++slot)
+                  for (int ks = 0; ks < ksteps; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                      for (int q = 0; q < 8; ++q) {
+                        const int k = 32 * ks + 8 * (lane >> 4) + q, g = lane & 3, unit = 4 * (3 * wv + slot) + ((lane >> 2) & 3);
+                        if (k < width && unit < H)
+                          v[(((((size_t)dir * 8 + wv) * 4 + slot) * ksteps + ks) * 64 + lane) * 8 + q] =
+                              (_Float16)kern[dir][(size_t)(k_off + k) * 4 * H + g * H + unit];
+                      }
+            return v;
+          };
+          _Float16 *dx = nullptr, *dh = nullptr;
+          if ((st = dev_upload(e, &dx, frag(ksx, 0, lp.in_w)))) return st;
+          if ((st = dev_upload(e, &dh, frag(4, lp.in_w, H)))) return st;
           lp.wxwide = dx;
+          lp.whfused = dh;
           lp.wx_ksteps = ksx;
         }
       }
@@ -812,13 +820,14 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->lstm_paired = getenv("CHIRON_LSTM_PAIR") != nullptr;
   e->lstm_fixed_roles = getenv("CHIRON_LSTM_FIXED_ROLES") != nullptr;
   e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;
+  e->lstm16_pair = getenv("CHIRON_LSTM16_PAIR") != nullptr;
   {
-    // f16 engines whose padded batch gives every CU a 16-row workgroup per direction (configs[4]: 4096 -> 512) run the
-    // x-projection inside the recurrence (lstm16f_kernel); CHIRON_LSTM16_UNFUSED=1 keeps the projection GEMM + z (A/B switch)
-    hipDeviceProp_t prop;
-    int n_cu = 256;
-    if (hipGetDeviceProperties(&prop, e->opts.device_id) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-    e->lstm16_fused = e->f16 && !e->lstm16_narrow && desc->hidden == 100 && (e->BP / 16) * 2 >= n_cu && getenv("CHIRON_LSTM16_UNFUSED") == nullptr;
+    // f16 engines run the x-projection inside the recurrence (lstm16f_kernel) from 64 sixteen-row workgroups up (B >= 512:
+    // a workgroup alone on its CU takes 0.69 ms for T = 400 whatever the batch, the projection GEMMs + the 4-row recurrence
+    // take 0.66 ms at B = 512, 1.18 at 1100, 1.9 at 2048; measured per batch 2.04 vs 2.18 / 3.36 vs 4.12 / 5.33 vs 6.84 ms).
+    // CHIRON_LSTM16_UNFUSED=1 keeps the projection GEMM + z (A/B switch), CHIRON_LSTM16_FUSED_MIN=<workgroups> moves the threshold.
+    const int min_groups = getenv("CHIRON_LSTM16_FUSED_MIN") ? atoi(getenv("CHIRON_LSTM16_FUSED_MIN")) : 64;
+    e->lstm16_fused = e->f16 && !e->lstm16_narrow && desc->hidden == 100 && (e->BP / 16) * 2 >= min_groups && getenv("CHIRON_LSTM16_UNFUSED") == nullptr;
   }
   st = build_plans(e, weights);
   if (st == CHIRON_OK) {
@@ -1175,11 +1184,15 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.narrow16 = e->lstm16_narrow ? 1 : 0;
     r.xsrc = nullptr;
     r.wxwide = nullptr;
+    r.whfused = nullptr;
+    r.fused_pair = 0;
     r.xbias = nullptr;
     r.xK = r.xld = r.x_time_major = 0;
     if (fused) {
       r.xsrc = l == 0 ? (const void*)fea : (const void*)prev;
       r.wxwide = lp.wxwide;
+      r.whfused = lp.whfused;
+      r.fused_pair = e->lstm16_pair ? 1 : 0;
       r.xbias = lp.proj[0].shift;
       r.xK = lp.in_w;
       r.xld = l == 0 ? e->C : e->lasth_ld;

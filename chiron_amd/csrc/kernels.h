@@ -103,7 +103,10 @@ struct LstmParams {
                          //   W_hh[k = 16 ks + 4 kq + e][gate*H + 4 tile + u], tile = 3 wave + slot (zero past K or the wave's tiles)
   // f16, fused with the x-projection (lstm16f_kernel; xsrc == nullptr: z comes from the projection GEMM as above)
   const void* xsrc;      // layer input, halves: [B][T][xld] (x_time_major 0: CNN features) or [T][BP][xld] (1: previous lasth)
-  const void* wxwide;    // [ndir][8 waves][4 tile slots][KSX k-steps][64 lanes][4 halves]: W_x in the order of wwide, KSX = 16 (K = 256) or 13
+  const void* wxwide;    // [ndir][8 waves][4 tile slots][KSX k-steps of 32][64 lanes][8 halves]: W_x, lane = kg*16 + 4u + gate ->
+                         //   W_x[k = 32 ks + 8 kg + e][gate*H + 4 tile + u]; KSX = 8 (K = 256) or 7 (K = 200)
+  const void* whfused;   // W_hh in the same order, 4 k-steps of 32 (K = 100 padded to 128)
+  int fused_pair;        // 1: two 16-row groups per workgroup (A/B switch CHIRON_LSTM16_PAIR)
   const float* xbias;    // [ndir][4H] bias + forget bias, column = gate*H + unit (the projection GEMM's shift vector)
   int xK, xld, x_time_major;
   const int32_t* seq_len;  // [BP] (0 for padded rows)

@@ -640,148 +640,192 @@ __global__ __launch_bounds__(64 * W16_NW, 2) void lstm16w_kernel(const LstmParam
 // its 16 input rows x_t (8 KB; the backward direction walks t = seq_len - 1 - s per row, so this is a per-row gather, not a
 // tile of a GEMM), and every wave multiplies them by ITS columns of W_x, resident in registers next to W_hh (KSX k-steps of
 // 16 x 2 registers per column tile; wave 7 with four tiles holds 184 weight registers: one workgroup per CU, 8 waves).
-//   x tile in LDS: [k quad][row][4 halves], the A-operand order of h (lane-linear 8-byte reads); thread (row = tid / 32,
-//   j = tid % 32) fetches the 16 bytes k = 8j .. 8j+7 of its row one step ahead and stores them as two quads.
-//   K = 200 (layers 1, 2) is padded to 208: the 26th piece of a row is never written and stays zero.
+//   MFMA: v_mfma_f32_16x16x32_f16 (gfx950's double-K form: the 16x16x16 instruction still takes 16 cycles on this chip, so
+//   it runs at half the f16 rate; measured 1.92 -> see DESIGN 3.5).  x and h tiles in LDS: [k octet][row][8 halves], the
+//   A-operand order (lane (row, kg) reads k = 32 s + 8 kg .. +7: lane-linear 16-byte reads); thread (row = tid / 32,
+//   j = tid % 32) fetches the 16 bytes k = 8j .. 8j+7 of its row one step ahead: exactly one octet.
+//   K = 200 (layers 1, 2) is padded to 224 (7 k-steps): the octets past the 25th are never written and stay zero;
+//   the hidden state's K = 100 is padded to 128 (4 k-steps).
 // ---------------------------------------------------------------------------------------------------------
-template <int KSX>
+constexpr int F16_KS = 4;        // fused kernel: k-steps of 32 over the hidden state (K = 100 padded to 128)
+constexpr int HF16 = 16 * 128;   // halves per h buffer of the fused kernel: [16 k octets][16 rows][8 halves]
+template <int KSX, int NG>
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParams p) {
-  constexpr int XQ = KSX * 4;                       // k quads of the x tile
-  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * HW16];
-  __shared__ __attribute__((aligned(16))) _Float16 xbuf[2 * XQ * 64];
-  __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * W16_XF];
+  // NG = 2: one workgroup carries TWO 16-row groups through the same weight registers (every weight fragment feeds two
+  // MFMAs): B = 4096 is then exactly one workgroup per CU, and a wave has two independent chains per step to hide the
+  // LDS / barrier / transcendental latencies that a single 8-wave workgroup per CU leaves exposed.
+  constexpr int XQ = KSX * 4;                       // k octets (8 halves) of the x tile: KSX k-steps of 32
+  constexpr int NTR = NG == 2 ? 3 : 4;              // column-tile slots whose W_x lives in registers (NG = 2: wave 7's fourth in LDS)
+  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * NG * HF16];
+  __shared__ __attribute__((aligned(16))) _Float16 xbuf[2 * NG * XQ * 128];
+  __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * NG * W16_XF];
+  __shared__ __attribute__((aligned(16))) _Float16 wx3[NG == 2 ? KSX * 64 * 8 : 8];   // wave 7, tile slot 3: W_x fragments
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dir = blockIdx.x % p.ndir;
-  const int g16 = blockIdx.x / p.ndir;
+  const int g0 = (blockIdx.x / p.ndir) * NG;        // first 16-row group of this workgroup
   const int nt = wave == W16_NW - 1 ? 4 : 3;
   const int tile0 = 3 * wave;
 
-  f16x4 wh[W16_NT][W16_KS], wx[W16_NT][KSX];
+  f16x8 wh[W16_NT][F16_KS], wx[NTR][KSX];
   {
-    const f16x4* wf = reinterpret_cast<const f16x4*>(p.wwide) + ((long)dir * W16_NW + wave) * W16_NT * W16_KS * 64 + lane;
+    const f16x8* wf = reinterpret_cast<const f16x8*>(p.whfused) + ((long)dir * W16_NW + wave) * W16_NT * F16_KS * 64 + lane;
 #pragma unroll
     for (int n = 0; n < W16_NT; ++n)
 #pragma unroll
-      for (int ks = 0; ks < W16_KS; ++ks) wh[n][ks] = wf[(n * W16_KS + ks) * 64];
-    const f16x4* xwf = reinterpret_cast<const f16x4*>(p.wxwide) + ((long)dir * W16_NW + wave) * W16_NT * KSX * 64 + lane;
+      for (int ks = 0; ks < F16_KS; ++ks) wh[n][ks] = wf[(n * F16_KS + ks) * 64];
+    const f16x8* xwf = reinterpret_cast<const f16x8*>(p.wxwide) + ((long)dir * W16_NW + wave) * W16_NT * KSX * 64 + lane;
 #pragma unroll
-    for (int n = 0; n < W16_NT; ++n)
+    for (int n = 0; n < NTR; ++n)
 #pragma unroll
       for (int ks = 0; ks < KSX; ++ks) wx[n][ks] = xwf[(n * KSX + ks) * 64];
+    if (NG == 2 && wave == W16_NW - 1) {
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) reinterpret_cast<f16x8*>(wx3)[ks * 64 + lane] = xwf[(3 * KSX + ks) * 64];
+    }
   }
-  for (int i = tid; i < 2 * HW16; i += 64 * W16_NW) hbuf[i] = (_Float16)0.f;
-  for (int i = tid; i < 2 * XQ * 64; i += 64 * W16_NW) xbuf[i] = (_Float16)0.f;
+  for (int i = tid; i < 2 * NG * HF16; i += 64 * W16_NW) hbuf[i] = (_Float16)0.f;
+  for (int i = tid; i < 2 * NG * XQ * 128; i += 64 * W16_NW) xbuf[i] = (_Float16)0.f;
 
   const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;
   const int row = 4 * q + gp;
-  const int brow = g16 * 16 + row;
-  const int lenr = min(p.seq_len[brow], p.T);
-  int maxlen = 0;
+  int lenr[NG], maxlen = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) maxlen = max(maxlen, min(p.seq_len[g16 * 16 + r], p.T));
+  for (int g = 0; g < NG; ++g) lenr[g] = min(p.seq_len[(g0 + g) * 16 + row], p.T);
+  for (int r = 0; r < 16 * NG; ++r) maxlen = max(maxlen, min(p.seq_len[g0 * 16 + r], p.T));
 
   // bias (+ forget bias) of this lane's column of each tile: the C operand the tile's first MFMA starts from
   float bias[W16_NT];
 #pragma unroll
   for (int n = 0; n < W16_NT; ++n) bias[n] = n < nt ? p.xbias[dir * 4 * p.H + gp * p.H + 4 * (tile0 + n) + u] : 0.f;
 
-  // ---- x loader: this thread's piece of the tile
+  // ---- x loader: this thread's piece (16 bytes: k = 8 xj .. 8 xj + 7 of row xr) of each group's tile
   const int xr = tid >> 5, xj = tid & 31;
   const bool xlive = 8 * xj < p.xK;
-  const int xb = g16 * 16 + xr;
-  const int xlen = min(p.seq_len[xb], p.T);
   const char* const xsrc = reinterpret_cast<const char*>(p.xsrc);
-  auto x_offset = [&](int s) -> unsigned {   // byte offset of the piece for step s (any valid frame for a finished row)
-    int t = dir == 0 ? s : xlen - 1 - s;
+  int xlen[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) xlen[g] = min(p.seq_len[(g0 + g) * 16 + xr], p.T);
+  auto x_offset = [&](int g, int s) -> unsigned {   // byte offset of the piece for step s (any valid frame for a finished row)
+    const int xb = (g0 + g) * 16 + xr;
+    int t = dir == 0 ? s : xlen[g] - 1 - s;
     t = min(max(t, 0), p.T - 1);
     // rows past the submitted batch have length 0 and are never consumed; they read row B - 1 (the feature tensor holds B rows)
     const unsigned r = p.x_time_major ? (unsigned)t * p.BP + xb : (unsigned)min(xb, p.B - 1) * p.T + t;
-    return (r * p.xld + 8 * xj) * 2u;
+    return (r * p.xld + (xlive ? 8 * xj : 0)) * 2u;
   };
-  const int xw0 = ((2 * xj) * 16 + xr) * 4;          // halves: quad 2j; quad 2j+1 is 64 halves further
+  const int xw0 = (xj * 16 + xr) * 8;                // halves: octet j of the row, [octet][row][8]
   __syncthreads();   // the zero fill above is complete before the first pieces land
   if (xlive && maxlen > 0) {
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xsrc + x_offset(0));
-    *reinterpret_cast<f32x2*>(xbuf + xw0) = (f32x2){x0[0], x0[1]};
-    *reinterpret_cast<f32x2*>(xbuf + xw0 + 64) = (f32x2){x0[2], x0[3]};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      *reinterpret_cast<f32x4*>(xbuf + g * XQ * 128 + xw0) = *reinterpret_cast<const f32x4*>(xsrc + x_offset(g, 0));
+    }
   }
   __syncthreads();
 
   const unsigned outw = p.ndir * p.H;
   const unsigned ostep = p.BP * outw;
-  const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;
-  const int hw = tile0 * 64 + row * 4 + u;
+  const unsigned olane = (g0 * 16 + row) * outw + dir * p.H + 4 * tile0 + u;   // + 16 outw per group, + 4 per tile
+  // cell (row, unit 4 T + u) of column tile T: octet T / 2, element 4 (T % 2) + u  ->  + 4 per tile, + 120 more every second
+  auto h_pos = [&](int n) -> int { const int T = tile0 + n; return ((T >> 1) * 16 + row) * 8 + 4 * (T & 1) + u; };
   _Float16* outh = reinterpret_cast<_Float16*>(p.out);
-  float* const xw = xf + wave * W16_NT * W16_XF + 4 * lane + 4 * q;
-  const float* const xrd = xf + wave * W16_NT * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+  float* const xw = xf + wave * W16_NT * NG * W16_XF + 4 * lane + 4 * q;
+  const float* const xrd = xf + wave * W16_NT * NG * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
 
-  float c[W16_NT] = {0.f, 0.f, 0.f, 0.f}, hprev[W16_NT] = {0.f, 0.f, 0.f, 0.f};
+  float c[NG][W16_NT];   // (the carried h of a finished row is re-read from the h tile: its only consumer is that tile)
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) c[g][n] = 0.f;
   int cur = 0;
   for (int s = 0; s < maxlen; ++s) {
-    // next step's piece, in flight during this step's arithmetic.  Issued by every lane on every step (lanes past K and the
-    // last step fetch a valid address and drop the data): the register must have the asm as its only definition, a merge
-    // with an older value would let the compiler copy it before the load has landed.
-    f32x4 xpre;
-    {
-      const char* src = xsrc + (xlive ? x_offset(s + 1) : x_offset(0) - 16u * xj);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xpre) : "v"(src) : "memory");
-    }
-    const f16x4* hb = reinterpret_cast<const f16x4*>(hbuf + cur * HW16) + lane;
-    const f16x4* xbp = reinterpret_cast<const f16x4*>(xbuf + cur * XQ * 64) + lane;
-    f32x4 acc[W16_NT];
+    // next step's pieces, in flight during this step's arithmetic.  Issued by every lane on every step (lanes past K and the
+    // last step fetch a valid address and drop the data): the registers must have the asm as their only definition, a merge
+    // with an older value would let the compiler copy them before the load has landed.
+    f32x4 xpre[NG];
 #pragma unroll
-    for (int n = 0; n < W16_NT; ++n) acc[n] = (f32x4){bias[n], bias[n], bias[n], bias[n]};
+    for (int g = 0; g < NG; ++g) {
+      const char* src = xsrc + x_offset(g, s + 1);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xpre[g]) : "v"(src) : "memory");
+    }
+    f32x4 acc[NG][W16_NT];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int n = 0; n < W16_NT; ++n) acc[g][n] = (f32x4){bias[n], bias[n], bias[n], bias[n]};
 #pragma unroll
     for (int ks = 0; ks < KSX; ++ks) {
-      const f16x4 xa = xbp[ks * 64];
+      f16x8 xa[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) xa[g] = reinterpret_cast<const f16x8*>(xbuf + (cur * NG + g) * XQ * 128)[ks * 64 + lane];
 #pragma unroll
       for (int n = 0; n < W16_NT; ++n)
-        if (n < nt) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(xa, wx[n][ks], acc[n], 0, 0, 0);
+        if (n < nt) {
+          f16x8 wv;
+          if (n < NTR) wv = wx[n < NTR ? n : 0][ks];
+          else wv = reinterpret_cast<const f16x8*>(wx3)[ks * 64 + lane];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[g], wv, acc[g][n], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int ks = 0; ks < W16_KS; ++ks) {
-      const f16x4 ha = hb[ks * 64];
+    for (int ks = 0; ks < F16_KS; ++ks) {
+      f16x8 ha[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ha[g] = reinterpret_cast<const f16x8*>(hbuf + (cur * NG + g) * HF16)[ks * 64 + lane];
 #pragma unroll
       for (int n = 0; n < W16_NT; ++n)
-        if (n < nt) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, wh[n][ks], acc[n], 0, 0, 0);
+        if (n < nt) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g) acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha[g], wh[n][ks], acc[g][n], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int n = 0; n < W16_NT; ++n)
-      if (n < nt) *reinterpret_cast<f32x4*>(xw + n * W16_XF) = acc[n];
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int n = 0; n < W16_NT; ++n)
+        if (n < nt) *reinterpret_cast<f32x4*>(xw + (g * W16_NT + n) * W16_XF) = acc[g][n];
     __builtin_amdgcn_wave_barrier();
-    const bool act = s < lenr;
-    const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
 #pragma unroll
-    for (int n = 0; n < W16_NT; ++n) {
-      if (n < nt) {
-        const float* xs = xrd + n * W16_XF;
-        const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};
-        float hnew;
-        const float cn = lstm_cell(gates, c[n], &hnew);
-        c[n] = act ? cn : c[n];
-        hprev[n] = act ? hnew : hprev[n];
-        hbuf[(cur ^ 1) * HW16 + hw + 64 * n] = (_Float16)hprev[n];
-        outh[to * ostep + olane + 4 * n] = (_Float16)(act ? hnew : 0.f);
+    for (int g = 0; g < NG; ++g) {
+      const bool act = s < lenr[g];
+      const unsigned to = (dir == 0 || !act) ? s : lenr[g] - 1 - s;
+#pragma unroll
+      for (int n = 0; n < W16_NT; ++n) {
+        if (n < nt) {
+          const float* xs = xrd + (g * W16_NT + n) * W16_XF;
+          const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};
+          float hnew;
+          const float cn = lstm_cell(gates, c[g][n], &hnew);
+          c[g][n] = act ? cn : c[g][n];
+          const _Float16 hold = hbuf[(cur * NG + g) * HF16 + h_pos(n)];
+          hbuf[((cur ^ 1) * NG + g) * HF16 + h_pos(n)] = act ? (_Float16)hnew : hold;
+          outh[to * ostep + olane + g * 16 * outw + 4 * n] = (_Float16)(act ? hnew : 0.f);
+        }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre) : : "memory");
+    if (NG == 2)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre[0]), "+v"(xpre[NG - 1]) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre[0]) : : "memory");
     if (xlive && s + 1 < maxlen) {
-      _Float16* xd = xbuf + (cur ^ 1) * XQ * 64 + xw0;
-      *reinterpret_cast<f32x2*>(xd) = (f32x2){xpre[0], xpre[1]};
-      *reinterpret_cast<f32x2*>(xd + 64) = (f32x2){xpre[2], xpre[3]};
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        *reinterpret_cast<f32x4*>(xbuf + ((cur ^ 1) * NG + g) * XQ * 128 + xw0) = xpre[g];
+      }
     }
     cur ^= 1;
     __syncthreads();
   }
 
   for (int s = maxlen; s < p.T; ++s)
-    for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
+    for (int i = tid; i < 16 * NG * p.H; i += 64 * W16_NW) {
       const int r = i / p.H;
       const int uu = i - r * p.H;
-      outh[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
+      outh[((long)s * p.BP + g0 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
     }
 }
 
@@ -802,10 +846,19 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
   p.group0 = 0;
   const int groups = p.BP / 4;
   if (p.f16 && p.xsrc) {   // fused with the x-projection: the engine asks for it only when whole 16-row groups cover the batch
-    if (p.xK > 208)
-      hipLaunchKernelGGL(lstm16f_kernel<16>, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
-    else
-      hipLaunchKernelGGL(lstm16f_kernel<13>, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    // two 16-row groups per workgroup when the padded batch is whole 32-row pairs (4096: one workgroup per CU)
+    const int g16 = p.BP / 16;
+    if (g16 % 2 == 0 && p.fused_pair) {
+      if (p.xK > 224)
+        hipLaunchKernelGGL((lstm16f_kernel<8, 2>), dim3((g16 / 2) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+      else
+        hipLaunchKernelGGL((lstm16f_kernel<7, 2>), dim3((g16 / 2) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    } else {
+      if (p.xK > 224)
+        hipLaunchKernelGGL((lstm16f_kernel<8, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+      else
+        hipLaunchKernelGGL((lstm16f_kernel<7, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    }
     return;
   }
   if (p.f16) {

@@ -693,13 +693,19 @@ def test_f16_path_tolerance_vs_f32(dna, rna):
     """BASELINE configs[4]: fp16 conv + LSTM on the f16 MFMA instructions, fp32 accumulation / gates / CTC.
     Tolerance check against the fp32 engine on identical inputs (the fp32 engine is itself within 1e-4 of the
     oracle): logits within 0.08 absolute (fp16 has 11 bits of mantissa and three stacked BiLSTMs in between), the
-    greedy base strings identical on >= 97 % of the windows and never further than 2 edits apart."""
+    greedy base strings identical on >= 97 % of the windows and never further than 2 edits apart.  The 150- and 40-window
+    cases take the 4-row recurrence behind the projection GEMM; 520 windows cross the threshold of the fused 16-row form
+    (lstm16f_kernel: 528 padded rows = 66 workgroups) -- for DNA in all three layers, for the RNA MultiRNN graph in layer 0
+    only (its upper layers project each direction separately and keep the GEMM + z path), with a ragged and a zero-length
+    row inside a 16-row group."""
     import difflib
-    for (spec, w), L, jump, n in ((dna, 400, 390, 150), (rna, 500, 490, 40)):
+    for (spec, w), L, jump, n in ((dna, 400, 390, 150), (rna, 500, 490, 40), (dna, 400, 390, 520), (rna, 500, 490, 520)):
         x, ln = _windows(jump * (n - 1) + 123, L, jump, seed=41)
         B = x.shape[0]
         ln = ln.copy()
         ln[1] = L // 3                                           # one ragged row besides the short last window
+        if B > 300:
+            ln[[18, 257]] = [0, 7]
         with ca.Engine(spec, w, max_batch=B, segment_len=L) as e32:
             sl = ca.seq_len_for_engine(ln, e32.ratio)
             r32 = e32.infer(x, sl, want_prob=True, want_logits=True)
@@ -715,7 +721,7 @@ def test_f16_path_tolerance_vs_f32(dna, rna):
         rows16 = _check_decode(r16, r16.logits, sl, B)            # the decoders run in fp32 on the f16 logits
         rows32 = _check_decode(r32, r32.logits, sl, B)
         same = sum(a == b for a, b in zip(rows16, rows32))
-        assert same >= 0.97 * B, (same, B)
+        assert same >= (0.97 if B <= 300 else 0.95) * B, (same, B)   # 4096 windows measure 96.1 % (config5 test): 95 % there and here
         for a, b in zip(rows16, rows32):
             if a != b:
                 sm = difflib.SequenceMatcher(None, a, b, autojunk=False)
