@@ -217,6 +217,7 @@ struct chiron_engine {
   chiron_engine_opts opts;
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
+  bool stream16 = true;           // f16: 1 x 1 convolutions on the streaming kernel (CHIRON_NO_STREAM16=1: gemm.hip, A/B switch)
   bool lstm16_pair = false;       // f16 fused recurrence: two 16-row groups per workgroup (A/B switch)
   bool lstm16_fused = false;      // f16: x-projection inside the recurrence (whole 16-row groups that fill the CUs)
   bool lstm16_narrow = false;     // A/B switch: f16 recurrence on 4-row workgroups only
@@ -821,6 +822,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->lstm_fixed_roles = getenv("CHIRON_LSTM_FIXED_ROLES") != nullptr;
   e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;
   e->lstm16_pair = getenv("CHIRON_LSTM16_PAIR") != nullptr;
+  e->stream16 = getenv("CHIRON_NO_STREAM16") == nullptr;
   {
     // f16 engines run the x-projection inside the recurrence (lstm16f_kernel) from 64 sixteen-row workgroups up (B >= 512:
     // a workgroup alone on its CU takes 0.69 ms for T = 400 whatever the batch, the projection GEMMs + the 4-row recurrence
@@ -911,6 +913,7 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
 static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
   if (e->split) g.f16 = 2;  // same 4-byte element units as fp32; only the content of the 128-byte blocks differs
   if (e->f16) {
+    if (e->stream16 && launch_stream16(g, stream)) return true;   // 256 -> 256 channel 1 x 1 convolutions: streaming kernel
     g.f16 = 1;
     for (int i = 0; i < g.nseg; ++i) {
       g.seg[i].lda /= 2;

@@ -74,6 +74,9 @@ struct GemmParams {
 };
 
 bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel for this shape / dtype
+// fp16 engine, 1 x 1 convolutions with 256 channels in and out (stream16.hip): weights in registers, activations streamed through
+// the LDS.  Takes GemmParams in ELEMENT units (before launch()'s conversion to 4-byte units); false: shape not covered.
+bool launch_stream16(const GemmParams& p, hipStream_t stream);
 
 // 1 x 3 stride-1 convolution in Winograd F(2,3) form (wino.hip): fp32, channels-last, T even, C % 32 == 0, N % 64 == 0
 struct WinoParams {

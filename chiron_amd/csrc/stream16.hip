@@ -1,0 +1,169 @@
+// fp16 engine: the 1 x 1 convolutions of a residual block (cnn.py:234-262: branch2/conv2a, and branch2/conv2c fused
+// with the branch1 convolution) as a STREAMING kernel: weights in registers, the LDS as a deep FIFO of activation rows.
+//
+// Why.  At f16 these launches carry 8x less matrix-pipe work per byte than at fp32 (BASELINE configs[4], B = 4096: 0.84 GB in,
+// 0.84 GB out, 0.2 ms of MFMA), and the tiled GEMM (gemm.hip) spends its LDS on double-buffered A AND weight tiles: one 32 KB
+// chunk in flight per workgroup, 64 KB per CU, ~3.5 us per chunk -- it runs at DMA latency, 2.3 TB/s of HBM.  Here
+//   * the whole weight matrix lives in VGPRs for the lifetime of the (persistent, one per CU) workgroup: wave w owns output
+//     columns 32w .. 32w+31 for every k -- 64 registers per 256-channel K-segment (A operand of v_mfma_f32_32x32x16_f16,
+//     the product is computed transposed, D = W^T x^T, so that a lane ends up with 4 x 4 CONSECUTIVE columns of one row);
+//   * the LDS holds nothing but activation tiles: 32 rows x 256 channels = 16 KB per K-segment, laid out
+//     [k octet][row][8 halves] = the B-operand order (lane (row, kh) reads octet 2 ks + kh: lane-linear 16-byte reads), six
+//     tiles deep (96 KB in flight per CU against 64 KB shared with weights before);
+//   * two PRODUCER waves do nothing but issue the LDS-DMA of tile i + D - 1 and wait for tile i: their vmcnt sees only loads,
+//     which return in order, so a partial s_waitcnt vmcnt(n) is exact; the eight compute waves' vmcnt holds only their stores.
+//     Producer and consumers meet at one s_barrier per tile.
+// Per tile a compute wave issues 16 (32) MFMAs of 32 cycles and 4 eight-byte stores per lane: the kernel is HBM-bound by
+// construction.  NSEG = 2 is conv2c + branch1: two K-segments (the block's conv2b output and the block's input) into one
+// accumulator.  Applicable when the engine is f16, C_in = C_out = 256, stride 1 (res_layer2 / res_layer3 of DNA_default
+// and their RNA counterparts); every other shape keeps gemm.hip.
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace chiron {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+constexpr unsigned S_OOB = 0xFFFF0000u;      // byte offset past num_records: the DMA writes zeros
+constexpr unsigned S_RECORDS = 0xFFFE0000u;  // every tensor of the engine is smaller than this many bytes
+constexpr int S_ROWS = 32;                   // rows per tile
+constexpr int S_C = 256;                     // channels per K-segment = output columns
+constexpr int S_TILE_H = S_ROWS * S_C;       // halves per segment tile (16 KB)
+constexpr int S_NW = 8;                      // compute waves
+constexpr int S_NP = 2;                      // producer waves (S_NW, S_NW + 1): half of a tile's octets each
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t s_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, S_RECORDS, 0x00027000);
+}
+
+template <int NSEG>
+__global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kernel(const GemmParams p) {
+  constexpr int D = NSEG == 1 ? 6 : 4;                 // tiles resident in the LDS; D - 1 in flight behind the one being consumed
+  extern __shared__ __attribute__((aligned(16))) _Float16 tiles[];   // [D][NSEG][32 octets][32 rows][8 halves]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  __shared__ __attribute__((aligned(16))) float shl[S_C];   // folded BN offset per output column
+  if (p.M < 0) tiles[tid] = (_Float16)0.f;   // the tiles are only ever written by the DMA engine (see gemm.hip)
+  if (tid < S_C) shl[tid] = p.shift ? p.shift[tid] : 0.f;
+  __syncthreads();
+
+  const int ntiles = (p.M + S_ROWS - 1) / S_ROWS;
+  const int first = blockIdx.x, step = gridDim.x;
+  const int mine = first < ntiles ? (ntiles - first + step - 1) / step : 0;   // tiles of this workgroup
+  if (mine == 0) return;
+
+  if (wave >= S_NW) {
+    // ---------------- producers: 16 DMA instructions per segment and tile (two octets x 32 rows each), 8 per producer wave
+    const int pw = wave - S_NW;
+    // (an array of __amdgpu_buffer_rsrc_t with a template-dependent bound makes hipcc 7.2 drop the kernel's host stub)
+    __amdgpu_buffer_rsrc_t rs[2];
+    rs[0] = s_rsrc(p.seg[0].src);
+    rs[1] = s_rsrc(p.seg[NSEG - 1].src);
+    auto issue = [&](int j) {   // tile number j of this workgroup (past the last one: zeros, no memory traffic)
+      const int m = (first + j * step) * S_ROWS + li;
+      const bool ok = j < mine && m < p.M;
+      _Float16* base = tiles + (j % D) * NSEG * S_TILE_H;
+#pragma unroll
+      for (int sg = 0; sg < NSEG; ++sg) {
+        const unsigned off = ok ? (unsigned)(((long)m * p.seg[sg].lda + p.seg[sg].col0) * 2 + kh * 16) : S_OOB;
+#pragma unroll
+        for (int o = 0; o < 16; o += 2)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[sg], (lptr_t)(base + sg * S_TILE_H + (pw * 16 + o) * S_ROWS * 8), 16,
+                                                   off + (unsigned)(pw * 16 + o) * 16u, 0, 0, 0);   // (the producer has VALU to spare)
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) issue(j);
+    for (int j = 0; j < mine; ++j) {
+      // everything but the D - 2 youngest tiles has landed: tile j is complete
+      constexpr int PENDING = (D - 2) * 8 * NSEG;   // this wave's DMA instructions of the D - 2 youngest tiles (<= 63)
+      static_assert(PENDING <= 63, "vmcnt is six bits");
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (PENDING & 15) | ((PENDING >> 4) << 14));   // vmcnt(PENDING); expcnt / lgkmcnt untouched
+      __builtin_amdgcn_s_barrier();        // consumers may read tile j; they have finished tile j - 1
+      issue(j + D - 1);                    // ... whose buffer is the one tile j + D - 1 goes to
+    }
+    return;
+  }
+
+  // ---------------- consumers: wave w owns output columns 32 w .. 32 w + 31
+  f16x8 wr[NSEG][16];
+  {
+    const _Float16* wt = reinterpret_cast<const _Float16*>(p.Wt) + (long)(32 * wave + li) * p.K + 8 * kh;
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg)
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) wr[sg][ks] = *reinterpret_cast<const f16x8*>(wt + sg * S_C + 16 * ks);
+  }
+  // D[i = column][j = row]: lane (row li), registers r -> column 32 w + 8 (r / 4) + 4 kh + r % 4
+  const float* const bias = shl + 32 * wave + 4 * kh;   // + 8 q: the four columns of register group q
+  _Float16* const outp = reinterpret_cast<_Float16*>(p.out) + 32 * wave + 4 * kh;
+  const bool relu = p.relu != 0;
+
+  for (int j = 0; j < mine; ++j) {
+    __builtin_amdgcn_s_barrier();          // tile j has landed
+    const _Float16* base = tiles + (j % D) * NSEG * S_TILE_H + (kh * S_ROWS + li) * 8;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg)
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const f16x8 xb = *reinterpret_cast<const f16x8*>(base + sg * S_TILE_H + ks * 2 * S_ROWS * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[sg][ks], xb, acc, 0, 0, 0);
+      }
+    const int m = (first + j * step) * S_ROWS + li;
+    if (m < p.M) {
+      _Float16* o = outp + (long)m * p.ldo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f16x4 hv;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[4 * q + r] + b4[r];
+          if (relu) v = __builtin_amdgcn_fmed3f(v, 0.f, INFINITY);
+          hv[r] = (_Float16)v;
+        }
+        *reinterpret_cast<f16x4*>(o + 8 * q) = hv;
+      }
+    }
+  }
+}
+
+// GemmParams in ELEMENT units (halves).  false: shape not covered, the caller takes gemm.hip.
+bool launch_stream16(const GemmParams& p, hipStream_t stream) {
+  if (p.out_mode != 0 || p.N != S_C || p.m_time_major || p.res_a != nullptr || p.sig != nullptr) return false;
+  if (p.nseg < 1 || p.nseg > 2 || p.K != p.nseg * S_C) return false;
+  for (int i = 0; i < p.nseg; ++i) {
+    const GemmSeg& s = p.seg[i];
+    if (s.src == nullptr || s.cin != S_C || s.kpad != S_C || s.stride != 1 || s.shift != 0 || s.time_major || s.w_in != p.T_out) return false;
+    if ((size_t)p.M * (size_t)s.lda * 2 > S_RECORDS) return false;
+  }
+  static int n_cu = 0;
+  static bool attr_ok = false;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 1 * S_TILE_H * 2) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * S_TILE_H * 2) == hipSuccess;
+    if (!attr_ok) (void)hipGetLastError();   // not sticky: the caller falls back to gemm.hip
+  }
+  if (!attr_ok) return false;
+  const int ntiles = (p.M + S_ROWS - 1) / S_ROWS;
+  const int grid = std::min(n_cu, ntiles);
+  if (p.nseg == 1)
+    hipLaunchKernelGGL(conv1x1_f16_stream_kernel<1>, dim3(grid), dim3(64 * (S_NW + S_NP)), (size_t)6 * 1 * S_TILE_H * 2, stream, p);
+  else
+    hipLaunchKernelGGL(conv1x1_f16_stream_kernel<2>, dim3(grid), dim3(64 * (S_NW + S_NP)), (size_t)4 * 2 * S_TILE_H * 2, stream, p);
+  return true;
+}
+
+}  // namespace chiron

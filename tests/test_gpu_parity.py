@@ -738,6 +738,29 @@ def _levenshtein(a, b):
     return prev[-1]
 
 
+def test_f16_streaming_conv_equals_tiled_gemm_form(dna, rna, monkeypatch):
+    """stream16.hip (1 x 1 convolutions of res_layer2 / res_layer3 with the weights in registers and the activations streamed
+    through the LDS by producer waves) against the tiled DMA GEMM of gemm.hip (CHIRON_NO_STREAM16=1) in the fp16 engine: the
+    same f16 products accumulated in fp32 in a different order, then rounded to f16 -- logits within 5e-3 (a last-bit flip
+    of an f16 activation is 1e-3 relative), batch sizes that leave a partial last 32-row tile, DNA and the RNA topology."""
+    for (spec, w), L, jump, n in ((dna, 400, 390, 37), (rna, 500, 490, 21)):
+        x, ln = _windows(jump * (n - 1) + 123, L, jump, seed=43)
+        out = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("CHIRON_NO_STREAM16", "1")
+            else:
+                monkeypatch.delenv("CHIRON_NO_STREAM16", raising=False)
+            with ca.Engine(spec, w, max_batch=x.shape[0], segment_len=L, dtype="fp16") as eng:
+                sl = ca.seq_len_for_engine(ln, eng.ratio)
+                out.append(eng.infer(x, sl, want_logits=True).logits.copy())
+        monkeypatch.delenv("CHIRON_NO_STREAM16", raising=False)
+        T = out[0].shape[1]
+        mask = np.arange(T)[None, :] < sl[:, None]
+        d = np.abs(out[0] - out[1])[mask]
+        assert np.isfinite(out[0]).all() and d.max() < 5e-3, d.max()
+
+
 def test_f16_recurrence_forms_agree(dna, monkeypatch):
     """The three forms of the fp16 recurrence (lstm.hip) on one batch of 4108 rows (padded to 4112 = 257 sixteen-row groups per
     direction) with zero-length, one-frame and ragged rows at the start, in the middle and at the end:
