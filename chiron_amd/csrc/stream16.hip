@@ -136,13 +136,137 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kern
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The 1 x 3 convolution (branch2/conv2b, stride 1, 256 -> 256) in the same style.  Its weights are 384 KB of halves -- more
+// than a CU's registers can spare -- so the output columns are split over TWO workgroups (128 columns each: 96 weight
+// registers per lane) that stream the same rows; workgroups i and i + 8 form such a pair, i.e. they sit on the same XCD
+// and the second reader of a row finds it in that XCD's L2.  v_mfma_f32_16x16x32_f16: wave w owns 16 columns (A operand =
+// its W^T slice for the three taps, 3 x 8 k-steps x 4 registers), B = 16 rows x 32 k from the LDS, two row halves per tile.
+//   tile in LDS: [40 row slots][32 octets][8 halves], ROW-major so that one DMA instruction fetches two whole 512-byte rows
+//   (an octet-major tile makes every instruction touch 34 cache lines for 16 bytes each: measured 0.83 ms per launch
+//   instead of the 1.01 ms of the tiled GEMM, L2-request bound); slot s holds row m0 - 1 + s for s < 34 (one halo row on
+//   either side), slots 34..39 are never fetched (the DMA writes zeros for them) and serve as the row of zeros that SAME
+//   padding needs where a tile row is the first or last position of its sequence.  The octets of slot s are stored
+//   permuted, logical octet o at position o ^ (s & 7) -- applied to the GLOBAL address of the fetching lane, the LDS side of
+//   a DMA is lane-linear -- so that the 16 rows of a B-operand read spread over the banks.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int S3_SLOTS = 40;                     // row slots per tile
+constexpr int S3_TILE_H = S3_SLOTS * S_C;        // halves per tile (20 KB)
+constexpr int S3_D = 6;                          // tiles resident
+constexpr int S3_ZERO = 36;                      // a slot that is always zero
+
+__global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv3_f16_stream_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 tiles[];   // [S3_D][40 slots][32 octets][8 halves]
+  __shared__ __attribute__((aligned(16))) float shl[S_C];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (p.M < 0) tiles[tid] = (_Float16)0.f;
+  if (tid < S_C) shl[tid] = p.shift ? p.shift[tid] : 0.f;
+  __syncthreads();
+
+  const int half = (blockIdx.x >> 3) & 1;                          // column half of this workgroup
+  const int stream_id = (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3);   // which of the gridDim.x / 2 row streams
+  const int nstreams = gridDim.x >> 1;
+  const int ntiles = (p.M + S_ROWS - 1) / S_ROWS;
+  const int mine = stream_id < ntiles ? (ntiles - stream_id + nstreams - 1) / nstreams : 0;
+  if (mine == 0) return;
+
+  if (wave >= S_NW) {
+    // ---------------- producers: 20 DMA instructions per tile (two slots each), 10 per producer wave
+    const int pw = wave - S_NW;
+    const __amdgpu_buffer_rsrc_t rs = s_rsrc(p.seg[0].src);
+    auto issue = [&](int j) {
+      _Float16* base = tiles + (j % S3_D) * S3_TILE_H;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        const int slot = 2 * (pw * 10 + q) + (lane >> 5);
+        const int m = (stream_id + j * nstreams) * S_ROWS - 1 + slot;
+        const bool ok = j < mine && slot < S_ROWS + 2 && m >= 0 && m < p.M;
+        const unsigned off = ok ? (unsigned)(((long)m * p.seg[0].lda + p.seg[0].col0) * 2 + (((lane & 31) ^ (slot & 7)) * 16)) : S_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(base + (pw * 10 + q) * 2 * S_C), 16, off, 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < S3_D - 1; ++j) issue(j);
+    for (int j = 0; j < mine; ++j) {
+      constexpr int PENDING = (S3_D - 2) * 10;
+      static_assert(PENDING <= 63, "vmcnt is six bits");
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (PENDING & 15) | ((PENDING >> 4) << 14));
+      __builtin_amdgcn_s_barrier();
+      issue(j + S3_D - 1);
+    }
+    return;
+  }
+
+  // ---------------- consumers: wave w owns output columns 128 half + 16 w .. + 15
+  const int ci = lane & 15, kg = lane >> 4;
+  const int col0 = 128 * half + 16 * wave;
+  f16x8 wr[3][8];
+  {
+    const _Float16* wt = reinterpret_cast<const _Float16*>(p.Wt) + (long)(col0 + ci) * p.K + 8 * kg;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) wr[tap][ks] = *reinterpret_cast<const f16x8*>(wt + tap * S_C + 32 * ks);
+  }
+  // D[i = column][n = row]: lane (row n = lane & 15), registers r -> column col0 + 4 kg + r
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(shl + col0 + 4 * kg);
+  _Float16* const outp = reinterpret_cast<_Float16*>(p.out) + col0 + 4 * kg;
+  const bool relu = p.relu != 0;
+  const int T = p.T_out;
+
+  for (int j = 0; j < mine; ++j) {
+    __builtin_amdgcn_s_barrier();
+    const int m0 = (stream_id + j * nstreams) * S_ROWS;
+    const _Float16* tb = tiles + (j % S3_D) * S3_TILE_H;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int rj = 16 * h + ci;                      // tile row of this lane
+      const int m = m0 + rj;
+      const int tpos = m % T;
+      // slots of the three taps: rows m - 1, m, m + 1 = slots rj, rj + 1, rj + 2; outside the sequence: the zero slot.
+      // k-step ks reads logical octet 4 ks + kg of its slot = position (4 ks + kg) ^ (slot & 7): 8 (ks >> 1) + e[ks & 1]
+      int sl[3] = {tpos == 0 ? S3_ZERO : rj, rj + 1, tpos == T - 1 ? S3_ZERO : rj + 2};
+      const _Float16* a[3][2];
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        a[tap][0] = tb + sl[tap] * S_C + ((kg ^ (sl[tap] & 7)) * 8);
+        a[tap][1] = tb + sl[tap] * S_C + (((4 + kg) ^ (sl[tap] & 7)) * 8);
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+          const f16x8 xv = *reinterpret_cast<const f16x8*>(a[tap][ks & 1] + (ks >> 1) * 64);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[tap][ks], xv, acc, 0, 0, 0);
+        }
+      }
+      if (m < p.M) {
+        f16x4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[r] + bias[r];
+          if (relu) v = __builtin_amdgcn_fmed3f(v, 0.f, INFINITY);
+          hv[r] = (_Float16)v;
+        }
+        *reinterpret_cast<f16x4*>(outp + (long)m * p.ldo) = hv;
+      }
+    }
+  }
+}
+
 // GemmParams in ELEMENT units (halves).  false: shape not covered, the caller takes gemm.hip.
 bool launch_stream16(const GemmParams& p, hipStream_t stream) {
   if (p.out_mode != 0 || p.N != S_C || p.m_time_major || p.res_a != nullptr || p.sig != nullptr) return false;
-  if (p.nseg < 1 || p.nseg > 2 || p.K != p.nseg * S_C) return false;
+  if (p.nseg < 1 || p.nseg > 3 || p.K != p.nseg * S_C) return false;
+  const bool taps = p.nseg == 3;   // conv2b: the three taps of one tensor
   for (int i = 0; i < p.nseg; ++i) {
     const GemmSeg& s = p.seg[i];
-    if (s.src == nullptr || s.cin != S_C || s.kpad != S_C || s.stride != 1 || s.shift != 0 || s.time_major || s.w_in != p.T_out) return false;
+    if (s.src == nullptr || s.cin != S_C || s.kpad != S_C || s.stride != 1 || s.time_major || s.w_in != p.T_out) return false;
+    if (s.shift != (taps ? i - 1 : 0) || (taps && (s.src != p.seg[0].src || s.lda != p.seg[0].lda || s.col0 != p.seg[0].col0))) return false;
     if ((size_t)p.M * (size_t)s.lda * 2 > S_RECORDS) return false;
   }
   static int n_cu = 0;
@@ -153,12 +277,19 @@ bool launch_stream16(const GemmParams& p, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
     attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 1 * S_TILE_H * 2) == hipSuccess &&
-              hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * S_TILE_H * 2) == hipSuccess;
+              hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * S_TILE_H * 2) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_f16_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S3_D * S3_TILE_H * 2) == hipSuccess;
     if (!attr_ok) (void)hipGetLastError();   // not sticky: the caller falls back to gemm.hip
   }
   if (!attr_ok) return false;
   const int ntiles = (p.M + S_ROWS - 1) / S_ROWS;
   const int grid = std::min(n_cu, ntiles);
+  if (taps) {
+    // pairs of workgroups (i, i + 8) share a row stream: the grid is a whole number of 16-workgroup blocks
+    const int g3 = std::max(16, (std::min(n_cu, 2 * ntiles + 15) / 16) * 16);
+    hipLaunchKernelGGL(conv3_f16_stream_kernel, dim3(g3), dim3(64 * (S_NW + S_NP)), (size_t)S3_D * S3_TILE_H * 2, stream, p);
+    return true;
+  }
   if (p.nseg == 1)
     hipLaunchKernelGGL(conv1x1_f16_stream_kernel<1>, dim3(grid), dim3(64 * (S_NW + S_NP)), (size_t)6 * 1 * S_TILE_H * 2, stream, p);
   else
