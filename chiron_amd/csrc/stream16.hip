@@ -50,8 +50,10 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kern
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kh = lane >> 5;
   __shared__ __attribute__((aligned(16))) float shl[S_C];   // folded BN offset per output column
+  __shared__ __attribute__((aligned(16))) float rsl[S_C];   // res_layer1: folded scale of the branch1 convolution of the signal
   if (p.M < 0) tiles[tid] = (_Float16)0.f;   // the tiles are only ever written by the DMA engine (see gemm.hip)
   if (tid < S_C) shl[tid] = p.shift ? p.shift[tid] : 0.f;
+  if (tid < S_C) rsl[tid] = p.res_a ? p.res_a[tid] : 0.f;
   __syncthreads();
 
   const int ntiles = (p.M + S_ROWS - 1) / S_ROWS;
@@ -103,6 +105,8 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kern
   }
   // D[i = column][j = row]: lane (row li), registers r -> column 32 w + 8 (r / 4) + 4 kh + r % 4
   const float* const bias = shl + 32 * wave + 4 * kh;   // + 8 q: the four columns of register group q
+  const float* const resa = rsl + 32 * wave + 4 * kh;
+  const bool res = p.res_a != nullptr;                  // + sig[b][t * res_stride] * res_a[column] (gemm.hip gemm_epilogue_lean<RES>)
   _Float16* const outp = reinterpret_cast<_Float16*>(p.out) + 32 * wave + 4 * kh;
   const bool relu = p.relu != 0;
 
@@ -120,13 +124,20 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kern
     const int m = (first + j * step) * S_ROWS + li;
     if (m < p.M) {
       _Float16* o = outp + (long)m * p.ldo;
+      float sv = 0.f;
+      if (res) {
+        const int b = m / p.T_out, t = m - b * p.T_out;
+        sv = p.sig[(long)b * p.L + (long)t * p.res_stride];
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f16x4 hv;
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(resa + 8 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[4 * q + r] + b4[r];
+          v = fmaf(sv, r4[r], v);
           if (relu) v = __builtin_amdgcn_fmed3f(v, 0.f, INFINITY);
           hv[r] = (_Float16)v;
         }
@@ -260,7 +271,9 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv3_f16_stream_kernel
 
 // GemmParams in ELEMENT units (halves).  false: shape not covered, the caller takes gemm.hip.
 bool launch_stream16(const GemmParams& p, hipStream_t stream) {
-  if (p.out_mode != 0 || p.N != S_C || p.m_time_major || p.res_a != nullptr || p.sig != nullptr) return false;
+  if (p.out_mode != 0 || p.N != S_C || p.m_time_major || (p.res_a != nullptr && (p.sig == nullptr || p.nseg != 1))) return false;
+  for (int i = 0; i < p.nseg; ++i)
+    if (p.seg[i].src == nullptr) return false;   // lifted segments (A computed from the signal) stay with gemm.hip
   if (p.nseg < 1 || p.nseg > 3 || p.K != p.nseg * S_C) return false;
   const bool taps = p.nseg == 3;   // conv2b: the three taps of one tensor
   for (int i = 0; i < p.nseg; ++i) {
