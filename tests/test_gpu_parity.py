@@ -761,6 +761,49 @@ def test_f16_streaming_conv_equals_tiled_gemm_form(dna, rna, monkeypatch):
         assert np.isfinite(out[0]).all() and d.max() < 5e-3, d.max()
 
 
+def test_f16_fused_recurrence_on_random_ragged_batches(dna, rna, monkeypatch):
+    """lstm16f_kernel forced onto small engines (CHIRON_LSTM16_FUSED_MIN=1: any number of 16-row workgroups) so that its
+    edges are hit: batches smaller than max_batch (rows past the submitted batch read a clamped input row and must stay
+    inert), zero-length and one-frame rows, every row of a 16-row group finished early (the group leaves the step loop and
+    zero-fills its frames), segment lengths that change T, the RNA graph (layer 0 fused, MultiRNN layers on the GEMM + z
+    path).  Reference: the same engine with CHIRON_LSTM16_UNFUSED=1 (logits within 1e-2, frames past a row's length bit for
+    bit) and the fp32 engine (0.08)."""
+    rng = np.random.RandomState(77)
+    cases = [(dna, 400, 5, 5), (dna, 400, 17, 48), (dna, 300, 33, 33), (rna, 500, 16, 20), (dna, 400, 70, 100), (rna, 500, 37, 37)]
+    for (spec, w), L, B, max_batch in cases:
+        x = ca.synthetic_signal(1, B * L, seed=300 + B)[0].reshape(B, L).copy()
+        ln = rng.randint(0, L + 1, size=B)
+        ln[rng.randint(0, B)] = L
+        if B >= 17:
+            ln[:16] = rng.randint(0, L // 4, size=16)       # a whole 16-row group that finishes early
+            ln[3] = 0
+            ln[4] = 1
+        for b in range(B):
+            x[b, ln[b]:] = 0
+        out = {}
+        for name, var in (("fused", "CHIRON_LSTM16_FUSED_MIN"), ("unfused", "CHIRON_LSTM16_UNFUSED")):
+            for v in ("CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED"):
+                monkeypatch.delenv(v, raising=False)
+            monkeypatch.setenv(var, "1")
+            with ca.Engine(spec, w, max_batch=max_batch, segment_len=L, n_slots=2, dtype="fp16") as eng:
+                sl = ca.seq_len_for_engine(ln, eng.ratio)
+                a = eng.infer(x, sl, want_logits=True, slot=0)
+                b2 = eng.infer(x, sl, want_logits=True, slot=1)
+                assert np.array_equal(a.logits, b2.logits)
+                out[name] = a.logits.copy()
+        for v in ("CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED"):
+            monkeypatch.delenv(v, raising=False)
+        with ca.Engine(spec, w, max_batch=max_batch, segment_len=L) as e32:
+            ref = e32.infer(x, sl, want_logits=True).logits
+        T = ref.shape[1]
+        mask = np.arange(T)[None, :] < sl[:, None]
+        assert np.isfinite(out["fused"]).all()
+        assert np.array_equal(out["fused"][~mask].view(np.uint32), out["unfused"][~mask].view(np.uint32)), (L, B)
+        if mask.any():
+            assert np.abs(out["fused"] - out["unfused"])[mask].max() < 1e-2, (L, B)
+            assert np.abs(out["fused"] - ref)[mask].max() < 0.08, (L, B)
+
+
 def test_f16_recurrence_forms_agree(dna, monkeypatch):
     """The three forms of the fp16 recurrence (lstm.hip) on one batch of 4108 rows (padded to 4112 = 257 sixteen-row groups per
     direction) with zero-length, one-frame and ragged rows at the start, in the middle and at the end:
