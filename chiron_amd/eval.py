@@ -111,12 +111,17 @@ def qs(consensus, consensus_qs, output_standard="phred+33"):
     if n_col == 0:
         return np.zeros(0, dtype=int) if output_standard == "number" else ""
     top = counts.shape[0] - 1 - np.argmax(counts[::-1], axis=0)      # last index among the maxima
-    n1 = counts[top, np.arange(n_col)]
-    n2 = np.partition(counts, -2, axis=0)[-2]
-    q_top = np.asarray(consensus_qs, dtype=np.float64)[top, np.arange(n_col)]
+    n1 = np.take_along_axis(counts, top[None, :], axis=0)[0]
+    rest = counts.copy()                                             # second largest count: the maximum without the winner
+    np.put_along_axis(rest, top[None, :], -1.0, axis=0)
+    n2 = rest.max(axis=0)
+    q_top = np.take_along_axis(np.asarray(consensus_qs, dtype=np.float64), top[None, :], axis=0)[0]
     voted = n1 > 0
-    score = np.zeros(n_col)
-    score[voted] = 10 * np.log10((n1[voted] + 1) / (n2[voted] + 1)) + q_top[voted] / n1[voted] / np.log(10)
+    if voted.all():
+        score = 10 * np.log10((n1 + 1) / (n2 + 1)) + q_top / n1 / np.log(10)
+    else:
+        score = np.zeros(n_col)
+        score[voted] = 10 * np.log10((n1[voted] + 1) / (n2[voted] + 1)) + q_top[voted] / n1[voted] / np.log(10)
     score = score.astype(int)
     if output_standard == "number":
         return score
@@ -136,20 +141,29 @@ class OutputTree(object):
         self.root, self.suffix, self.concise, self.rna = root, suffix, concise, rna
 
     def _path(self, folder, file_pre, ext):
-        path = os.path.join(self.root, folder, file_pre + "." + ext)
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        return path
+        return os.path.join(self.root, folder, file_pre + "." + ext)
+
+    @staticmethod
+    def _write(path, text):
+        """One write per file; the folder is created on demand (a recursive input puts sub-folders into file_pre)."""
+        try:
+            f = open(path, "w")
+        except FileNotFoundError:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            f = open(path, "w")
+        with f:
+            f.write(text)
 
     def consensus(self, file_pre, sequence, quality=None):
         """result/<pre>.fastq = @name / sequence / + / quality (each line terminated); result/<pre>.fasta = >name /
         sequence WITHOUT a final newline (chiron_eval.py:216-221)."""
         if self.rna:                                          # chiron_eval.py:204-205
             sequence = sequence.replace("T", "U").replace("t", "u")
-        with open(self._path("result", file_pre, self.suffix), "w") as f:
-            if self.suffix == "fastq" and quality is not None:
-                f.write("@%s\n%s\n+\n%s\n" % (file_pre, sequence, quality))
-            else:
-                f.write(">%s\n%s" % (file_pre, sequence))
+        if self.suffix == "fastq" and quality is not None:
+            text = "@%s\n%s\n+\n%s\n" % (file_pre, sequence, quality)
+        else:
+            text = ">%s\n%s" % (file_pre, sequence)
+        self._write(self._path("result", file_pre, self.suffix), text)
         return sequence
 
     def segments(self, file_pre, reads, qualities=None):
@@ -160,8 +174,7 @@ class OutputTree(object):
             records.append(">%s%d\n%s\n" % (file_pre, k, read))
             if self.suffix == "fastq" and qualities is not None:
                 records.append("@%s%d\n%s\n+\n%s\n" % (file_pre, k, read, qualities[k]))
-        with open(self._path("segments", file_pre, self.suffix), "w") as f:
-            f.write("".join(records))
+        self._write(self._path("segments", file_pre, self.suffix), "".join(records))
 
     def meta(self, file_pre, n_bases, stamps, settings):
         """meta/<pre>.meta: stage durations derived from the cumulative stamps (start, reading, basecall, assembly) and
@@ -169,13 +182,13 @@ class OutputTree(object):
         start, reading, basecall_end, assembly_end = stamps
         total = time.time() - start
         spans = (reading, basecall_end - reading, assembly_end - basecall_end, total - assembly_end, total)
-        with open(self._path("meta", file_pre, "meta"), "w") as f:
-            f.write("# Reading Basecalling assembly output total rate(bp/s)\n")
-            f.write(" ".join("%5.3f" % v for v in spans + (n_bases / total,)) + "\n")
-            f.write("# read_len batch_size segment_len jump start_pos\n")
-            f.write("%d %d %d %d %d\n" % (n_bases, settings.batch_size, settings.segment_len, settings.jump, settings.start))
-            f.write("# input_name model_name\n")
-            f.write("%s %s\n" % (settings.input, settings.model))
+        self._write(self._path("meta", file_pre, "meta"),
+                    "# Reading Basecalling assembly output total rate(bp/s)\n"
+                    + " ".join("%5.3f" % v for v in spans + (n_bases / total,)) + "\n"
+                    + "# read_len batch_size segment_len jump start_pos\n"
+                    + "%d %d %d %d %d\n" % (n_bases, settings.batch_size, settings.segment_len, settings.jump, settings.start)
+                    + "# input_name model_name\n"
+                    + "%s %s\n" % (settings.input, settings.model))
 
 
 def write_output(segments, consensus, time_list, file_pre, global_setting, concise=False, suffix="fasta",

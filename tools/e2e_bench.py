@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end `chiron call` throughput on synthetic reads (host pipeline + engine): N reads x 100k samples written
-as .signal files, then chiron_amd.eval.evaluation with the DNA preset.  usage: e2e_bench.py [n_reads] [beam] [fmt]"""
+as .signal files, then chiron_amd.eval.evaluation with the DNA preset.
+usage: e2e_bench.py [n_reads] [beam] [profile|timeline|-] [dtype] [batch]"""
 import cProfile
 import os
 import pstats
@@ -21,6 +22,8 @@ def main():
     beam = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     prof = len(sys.argv) > 3 and sys.argv[3] == "profile"
     timeline = len(sys.argv) > 3 and sys.argv[3] == "timeline"
+    dtype = sys.argv[4] if len(sys.argv) > 4 else "fp32"
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else 1100
     d = tempfile.mkdtemp(prefix="e2e_")
     inp = os.path.join(d, "in")
     os.makedirs(inp)
@@ -33,12 +36,12 @@ def main():
 
     class F(object):
         input, output, model = inp, os.path.join(d, "out"), "synthetic"
-        start, batch_size, segment_len, jump = 0, 1100, 400, 390
+        start, batch_size, segment_len, jump = 0, batch, 400, 390
         extension, concise, mode, recursive = "fastq", False, "dna", True
     F.beam = beam
     spec = ca.dna_default_spec()
     w = ca.synthetic_weights(spec, seed=1234)
-    with ca.Engine(spec, w, max_batch=1100, segment_len=400, n_slots=int(os.environ.get("E2E_SLOTS", "3")), max_beam=beam) as eng:
+    with ca.Engine(spec, w, max_batch=batch, segment_len=400, n_slots=int(os.environ.get("E2E_SLOTS", "3")), max_beam=beam, dtype=dtype) as eng:
         ce.evaluation(F, engine=eng)          # warm-up (page cache, first launches)
         shutil.rmtree(F.output)
         pr = cProfile.Profile() if prof else None
@@ -64,8 +67,8 @@ def main():
             pr.disable()
         dt = time.time() - t0
     windows = n_reads * 257
-    print("reads %d  windows %d  beam %d : %.2f s  -> %.0f windows/s, %.1f kbases/s (signal-normalised); input written in %.1f s"
-          % (n_reads, windows, beam, dt, windows / dt, windows * 390 / (4000 / 450.0) / 1000 / dt, t_write))
+    print("reads %d  windows %d  beam %d  %s batch %d : %.2f s  -> %.0f windows/s, %.1f kbases/s (signal-normalised); input written in %.1f s"
+          % (n_reads, windows, beam, dtype, batch, dt, windows / dt, windows * 390 / (4000 / 450.0) / 1000 / dt, t_write))
     if pr:
         pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
     if timeline:
