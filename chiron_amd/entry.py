@@ -86,6 +86,8 @@ def build_parser():
     p.add_argument("-l", "--segment_len", type=int, default=None, help="Segment length to be divided into.")
     p.add_argument("-j", "--jump", type=int, default=None, help="Step size for segment")
     p.add_argument("-t", "--threads", type=int, default=None, help="Host threads, 0 = all.")
+    p.add_argument("--finish-procs", type=int, default=0,
+                   help="Worker processes for consensus / quality / writers (0: threads; useful behind the fp16 engine).")
     p.add_argument("-e", "--extension", default="fastq", help="Output file type.")
     p.add_argument("--beam", type=int, default=None, help="Beam width of the CTC beam search decoder, 0 = greedy.")
     p.add_argument("--concise", action="store_true", help="Only write the result files.")

@@ -349,6 +349,19 @@ def finish_read(name, reads, qs_list, FLAGS, t_start, reading_time):
     return c_bpread
 
 
+_FLAG_FIELDS = ("input", "output", "model", "start", "batch_size", "segment_len", "jump", "extension", "concise", "mode", "device",
+                "device_vote_min_segments")
+
+
+def _finish_read_in_process(name, flat, seg_len, qs_list, flags, t_start, reading_time):
+    """finish_read for a worker PROCESS (FLAGS.finish_procs > 0): the decoded windows travel as one flat base array +
+    lengths, the settings as a plain dict.  The worker never touches the GPU."""
+    import argparse
+    ends = np.cumsum(seg_len)
+    reads = [flat[e - n:e] for e, n in zip(ends.tolist(), seg_len.tolist())]
+    return finish_read(name, reads, qs_list, argparse.Namespace(**flags), t_start, reading_time)
+
+
 def evaluation(FLAGS, engine=None, file_list=None):
     """chiron_eval.py:378-463 on one GPU.  `file_list` restricts the reads this process handles
     (per-read sharding across GPUs)."""
@@ -375,7 +388,17 @@ def evaluation(FLAGS, engine=None, file_list=None):
     # packs batches and talks to the engine.  Batches are packed in file order, so results do not depend on timing.
     n_threads = max(1, int(getattr(FLAGS, "threads", 0) or 4))
     readers = ThreadPoolExecutor(max_workers=n_threads)
-    finishers = ThreadPoolExecutor(max_workers=n_threads)
+    # Finishing (base strings, consensus vote, quality string, three files per read) is Python + numpy + native calls: as
+    # threads it is bound by the GIL at a few hundred reads per second, enough for the fp32 engine.  FLAGS.finish_procs > 0
+    # moves it to that many worker processes (spawned: they import the host modules only, never the engine).
+    n_procs = int(getattr(FLAGS, "finish_procs", 0) or 0)
+    if n_procs > 0:
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+        finishers = ProcessPoolExecutor(max_workers=n_procs, mp_context=multiprocessing.get_context("spawn"))
+        flag_dict = {k: getattr(FLAGS, k) for k in _FLAG_FIELDS if hasattr(FLAGS, k)}
+    else:
+        finishers = ThreadPoolExecutor(max_workers=n_threads)
     finishing = []
 
     def drain(slot):
@@ -385,7 +408,13 @@ def evaluation(FLAGS, engine=None, file_list=None):
         res = engine.collect(slot)
         inflight[slot] = None
         for name, reads, qs_list, meta in collector.add_batch(batch, res, want_qs):
-            finishing.append((name, finishers.submit(finish_read, name, reads, qs_list, FLAGS, meta[0], meta[1])))
+            if n_procs > 0:
+                seg_len = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
+                flat = np.concatenate(reads).astype(np.uint8) if len(reads) else np.zeros(0, dtype=np.uint8)
+                fut = finishers.submit(_finish_read_in_process, name, flat, seg_len, qs_list, flag_dict, meta[0], meta[1])
+            else:
+                fut = finishers.submit(finish_read, name, reads, qs_list, FLAGS, meta[0], meta[1])
+            finishing.append((name, fut))
 
     def launch(batch):
         slot = step[0] % engine.n_slots

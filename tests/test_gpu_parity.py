@@ -341,6 +341,17 @@ def test_pipeline_end_to_end_on_example_signal(dna, tmp_path):
     assert os.path.exists(os.path.join(F.output, "meta", "read1.meta"))
     assert open(os.path.join(F.output, "result", "tiny.fastq")).read().startswith("@tiny\n")
 
+    # the same run with the finishing stage in two worker processes (FLAGS.finish_procs): identical result / segments files
+    class G(F):
+        output = str(tmp_path / "out_procs")
+        finish_procs = 2
+    with ca.Engine(spec, w, max_batch=50, segment_len=400, n_slots=2) as eng:
+        out2 = ce.evaluation(G, engine=eng)
+    assert out2 == out
+    for sub in ("result", "segments"):
+        for name in sorted(os.listdir(os.path.join(F.output, sub))):
+            assert open(os.path.join(F.output, sub, name)).read() == open(os.path.join(G.output, sub, name)).read(), (sub, name)
+
 
 def test_paired_recurrence_workgroups_give_identical_bits(dna, monkeypatch):
     """lstm.hip lstm_kernel<2> (CHIRON_LSTM_PAIR=1: two 4-row groups per workgroup, 14 waves, for the rows that fit one

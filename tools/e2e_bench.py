@@ -39,6 +39,7 @@ def main():
         start, batch_size, segment_len, jump = 0, batch, 400, 390
         extension, concise, mode, recursive = "fastq", False, "dna", True
     F.beam = beam
+    F.finish_procs = int(os.environ.get("E2E_FINISH_PROCS", "0"))
     spec = ca.dna_default_spec()
     w = ca.synthetic_weights(spec, seed=1234)
     with ca.Engine(spec, w, max_batch=batch, segment_len=400, n_slots=int(os.environ.get("E2E_SLOTS", "3")), max_beam=beam, dtype=dtype) as eng:
