@@ -94,16 +94,42 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
       }
     }
   };
+  // fp16 engine: the prefetched unit stays in the halves it was loaded as and is converted when it is consumed -- converting
+  // in load_unit makes the conversion wait for the load, i.e. no prefetch at all (0.49 ms at B = 4096 for half the bytes the
+  // fp32 engine reads in 0.33 ms)
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const bool raw16 = p.f16 && !p.split;
+  auto load_raw16 = [&](int q, f16x4 (&r)[4]) {
+    const int t = q / nb4;
+    const int b = (q - t * nb4) * 4 + sub;
+    const long row = (long)t * p.BP + (b < p.B ? b : 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      r[s] = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      const int f = sl + 16 * s;
+      if (f < nl) r[s] = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.lasth) + row * 2 * H + 4 * f);
+    }
+  };
   f32x4 hn[4];
-  if (wave < nunits) load_unit(wave, hn);
+  f16x4 rn[4];
+  if (wave < nunits) {
+    if (raw16) load_raw16(wave, rn);
+    else load_unit(wave, hn);
+  }
   for (int q = wave; q < nunits; q += nwaves) {
     const int t = q / nb4;
     const int b = (q - t * nb4) * 4 + sub;
     const bool live = b < p.B;
     f32x4 h[4];
+    if (raw16) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) h[s] = hn[s];
-    if (q + nwaves < nunits) load_unit(q + nwaves, hn);  // the next unit's rows are in flight during this one's arithmetic
+      for (int s = 0; s < 4; ++s) h[s] = (f32x4){(float)rn[s][0], (float)rn[s][1], (float)rn[s][2], (float)rn[s][3]};
+      if (q + nwaves < nunits) load_raw16(q + nwaves, rn);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) h[s] = hn[s];
+      if (q + nwaves < nunits) load_unit(q + nwaves, hn);  // the next unit's rows are in flight during this one's arithmetic
+    }
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < CHIRON_KMAX; ++k) {
