@@ -33,6 +33,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+template <bool RAW16>
 __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
   const int lane = threadIdx.x & 63;
   const int sub = lane >> 4, sl = lane & 15;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
   // in load_unit makes the conversion wait for the load, i.e. no prefetch at all (0.49 ms at B = 4096 for half the bytes the
   // fp32 engine reads in 0.33 ms)
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  const bool raw16 = p.f16 && !p.split;
+  constexpr bool raw16 = RAW16;   // p.f16 && !p.split (launch_fc)
   auto load_raw16 = [&](int q, f16x4 (&r)[4]) {
     const int t = q / nb4;
     const int b = (q - t * nb4) * 4 + sub;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
   f32x4 hn[4];
   f16x4 rn[4];
   if (wave < nunits) {
-    if (raw16) load_raw16(wave, rn);
+    if constexpr (raw16) load_raw16(wave, rn);
     else load_unit(wave, hn);
   }
   for (int q = wave; q < nunits; q += nwaves) {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
     const int b = (q - t * nb4) * 4 + sub;
     const bool live = b < p.B;
     f32x4 h[4];
-    if (raw16) {
+    if constexpr (raw16) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) h[s] = (f32x4){(float)rn[s][0], (float)rn[s][1], (float)rn[s][2], (float)rn[s][3]};
       if (q + nwaves < nunits) load_raw16(q + nwaves, rn);
@@ -147,7 +148,10 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
 }
 
 void launch_fc(const FcParams& p, hipStream_t stream) {
-  hipLaunchKernelGGL(fc_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
+  if (p.f16 && !p.split)
+    hipLaunchKernelGGL(fc_kernel<true>, dim3(256 * 8), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(fc_kernel<false>, dim3(256 * 8), dim3(256), 0, stream, p);
 }
 
 // --------------------------------------------------------------------------------------------
