@@ -780,7 +780,8 @@ def test_f16_fused_recurrence_on_random_ragged_batches(dna, rna, monkeypatch):
     path).  Reference: the same engine with CHIRON_LSTM16_UNFUSED=1 (logits within 1e-2, frames past a row's length bit for
     bit) and the fp32 engine (0.08)."""
     rng = np.random.RandomState(77)
-    cases = [(dna, 400, 5, 5), (dna, 400, 17, 48), (dna, 300, 33, 33), (rna, 500, 16, 20), (dna, 400, 70, 100), (rna, 500, 37, 37)]
+    cases = [(dna, 400, 5, 5), (dna, 400, 17, 48), (dna, 300, 33, 33), (rna, 500, 16, 20), (dna, 400, 70, 100), (rna, 500, 37, 37),
+             (dna, 400, 30, 32)]
     for (spec, w), L, B, max_batch in cases:
         x = ca.synthetic_signal(1, B * L, seed=300 + B)[0].reshape(B, L).copy()
         ln = rng.randint(0, L + 1, size=B)
@@ -792,22 +793,29 @@ def test_f16_fused_recurrence_on_random_ragged_batches(dna, rna, monkeypatch):
         for b in range(B):
             x[b, ln[b]:] = 0
         out = {}
-        for name, var in (("fused", "CHIRON_LSTM16_FUSED_MIN"), ("unfused", "CHIRON_LSTM16_UNFUSED")):
-            for v in ("CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED"):
+        forms = [("fused", "CHIRON_LSTM16_FUSED_MIN"), ("unfused", "CHIRON_LSTM16_UNFUSED")]
+        if max_batch % 32 == 0:
+            forms.append(("pair", "CHIRON_LSTM16_PAIR"))     # two 16-row groups per workgroup (needs whole 32-row pairs)
+        for name, var in forms:
+            for v in ("CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED", "CHIRON_LSTM16_PAIR"):
                 monkeypatch.delenv(v, raising=False)
             monkeypatch.setenv(var, "1")
+            if name == "pair":
+                monkeypatch.setenv("CHIRON_LSTM16_FUSED_MIN", "1")
             with ca.Engine(spec, w, max_batch=max_batch, segment_len=L, n_slots=2, dtype="fp16") as eng:
                 sl = ca.seq_len_for_engine(ln, eng.ratio)
                 a = eng.infer(x, sl, want_logits=True, slot=0)
                 b2 = eng.infer(x, sl, want_logits=True, slot=1)
                 assert np.array_equal(a.logits, b2.logits)
                 out[name] = a.logits.copy()
-        for v in ("CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED"):
+        for v in ("CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED", "CHIRON_LSTM16_PAIR"):
             monkeypatch.delenv(v, raising=False)
         with ca.Engine(spec, w, max_batch=max_batch, segment_len=L) as e32:
             ref = e32.infer(x, sl, want_logits=True).logits
         T = ref.shape[1]
         mask = np.arange(T)[None, :] < sl[:, None]
+        if "pair" in out:   # same arithmetic as the single-group fused form: bit for bit
+            assert np.array_equal(out["pair"].view(np.uint32), out["fused"].view(np.uint32)), (L, B)
         assert np.isfinite(out["fused"]).all()
         assert np.array_equal(out["fused"][~mask].view(np.uint32), out["unfused"][~mask].view(np.uint32)), (L, B)
         if mask.any():
