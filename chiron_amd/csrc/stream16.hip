@@ -296,6 +296,7 @@ bool launch_stream16(const GemmParams& p, hipStream_t stream) {
   }
   if (!attr_ok) return false;
   const int ntiles = (p.M + S_ROWS - 1) / S_ROWS;
+  if (ntiles <= 0) return true;   // nothing to do
   const int grid = std::min(n_cu, ntiles);
   if (taps) {
     // pairs of workgroups (i, i + 8) share a row stream: the grid is a whole number of 16-workgroup blocks
