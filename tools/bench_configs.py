@@ -20,21 +20,22 @@ def run(name, spec, L, jump, B, beam, steps=20, dtype="fp32"):
     sig = ca.synthetic_signal(1, jump * (B - 1) + L, seed=5)[0]
     x, ln = signal_io.window_signal(sig, 0, jump, L)
     x, ln = x[:B], ln[:B]
-    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=2, max_beam=beam, dtype=dtype) as eng:
+    NS = int(os.environ.get("BENCH_SLOTS", "2"))
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=NS, max_beam=beam, dtype=dtype) as eng:
         sl = ca.seq_len_for_engine(ln, eng.ratio)
         for _ in range(2):
             eng.infer(x, sl, beam_width=beam)
         eng.sync()
         t0 = time.perf_counter()
-        pend = [False, False]
+        pend = [False] * NS
         nb = 0
         for i in range(steps):
-            s = i % 2
+            s = i % NS
             if pend[s]:
                 nb += eng.collect(s).decoded.values.shape[0]
             eng.submit(s, x, sl, beam_width=beam, want_prob=True)
             pend[s] = True
-        for s in (0, 1):
+        for s in range(NS):
             if pend[s]:
                 nb += eng.collect(s).decoded.values.shape[0]
         dt = time.perf_counter() - t0
