@@ -37,6 +37,16 @@ constexpr int S_TILE_H = S_ROWS * S_C;       // halves per segment tile (16 KB)
 constexpr int S_NW = 8;                      // compute waves
 constexpr int S_NP = 2;                      // producer waves (S_NW, S_NW + 1): half of a tile's octets each
 
+// s_barrier between producer and consumer waves.  The compiler does not know that the DMA engine writes the tiles, so it
+// must not move an LDS read of the next tile above the barrier (or keep one below it alive across it): the empty asm
+// statements are compiler-only fences, the hardware ordering is the barrier itself (no s_waitcnt vmcnt here -- a
+// __syncthreads() would make every compute wave wait for its own output stores once per tile).
+static __device__ __forceinline__ void tile_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t s_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, S_RECORDS, 0x00027000);
 }
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kern
       constexpr int PENDING = (D - 2) * 8 * NSEG;   // this wave's DMA instructions of the D - 2 youngest tiles (<= 63)
       static_assert(PENDING <= 63, "vmcnt is six bits");
       __builtin_amdgcn_s_waitcnt(0x0F70 | (PENDING & 15) | ((PENDING >> 4) << 14));   // vmcnt(PENDING); expcnt / lgkmcnt untouched
-      __builtin_amdgcn_s_barrier();        // consumers may read tile j; they have finished tile j - 1
+      tile_barrier();                      // consumers may read tile j; they have finished tile j - 1
       issue(j + D - 1);                    // ... whose buffer is the one tile j + D - 1 goes to
     }
     return;
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kern
   const bool relu = p.relu != 0;
 
   for (int j = 0; j < mine; ++j) {
-    __builtin_amdgcn_s_barrier();          // tile j has landed
+    tile_barrier();                        // tile j has landed
     const _Float16* base = tiles + (j % D) * NSEG * S_TILE_H + (kh * S_ROWS + li) * 8;
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv3_f16_stream_kernel
       constexpr int PENDING = (S3_D - 2) * 10;
       static_assert(PENDING <= 63, "vmcnt is six bits");
       __builtin_amdgcn_s_waitcnt(0x0F70 | (PENDING & 15) | ((PENDING >> 4) << 14));
-      __builtin_amdgcn_s_barrier();
+      tile_barrier();
       issue(j + S3_D - 1);
     }
     return;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv3_f16_stream_kernel
   const int T = p.T_out;
 
   for (int j = 0; j < mine; ++j) {
-    __builtin_amdgcn_s_barrier();
+    tile_barrier();
     const int m0 = (stream_id + j * nstreams) * S_ROWS;
     const _Float16* tb = tiles + (j % S3_D) * S3_TILE_H;
 #pragma unroll
