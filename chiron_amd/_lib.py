@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CHIRON_AMD_LIB") or os.path.join(_HERE, "csrc", "libc
 MAX_BLOCKS = 8
 CLASSES = 5
 
-ABI_VERSION = 3      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
+ABI_VERSION = 4      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
@@ -73,6 +73,7 @@ SYMBOLS = [
     ("chiron_engine_sync", C.c_int, [C.c_void_p]),
     ("chiron_engine_device_results", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("chiron_engine_features", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("chiron_engine_profile", C.c_int, [C.c_void_p, C.c_int32]),
     ("chiron_engine_profile_read", C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
     ("chiron_parse_signal_text", C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -81,7 +82,7 @@ SYMBOLS = [
     ("chiron_overlap_displacement", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
                                               C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("chiron_consensus_device", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
-                                          C.c_int64, C.POINTER(C.c_int64)]),
+                                          C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     ("chiron_crc32c", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("chiron_last_error", C.c_char_p, []),
     ("chiron_abi_version", C.c_int32, []),

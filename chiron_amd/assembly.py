@@ -113,8 +113,9 @@ def simple_assembly_qs(bpreads, qs_list, jump_step_ratio, error_rate=0.2, kernal
 
 
 def consensus_device(bpreads, qs_list, kernal, device_id=0):
-    """chiron_consensus_device: glue / stick displacements, vote, argmax and quality string of ONE read on the GPU
-    -> (consensus 'ACGT' string, Phred+33 string or None).  Equal to simple_assembly_qs + argmax + eval.qs."""
+    """chiron_consensus_device: glue / stick displacements, vote and argmax of ONE read on the GPU; the device returns the
+    vote summary (n1, n2, quality sum behind the winner) and the Phred characters are computed here by eval.qs's own
+    formula -> (consensus 'ACGT' string, Phred+33 string or None).  Equal to simple_assembly_qs + argmax + eval.qs."""
     kid = _kernal_id(kernal)
     if kernal == "simple":
         raise ValueError("the device vote covers the glue and stick kernels; simple displacements are host code")
@@ -122,10 +123,15 @@ def consensus_device(bpreads, qs_list, kernal, device_id=0):
     qs = None if qs_list is None else np.ascontiguousarray(np.asarray(qs_list, dtype=np.float64).reshape(len(bpreads), -1)[:, 0])
     cap = int(bases.shape[0]) + 1
     cons = np.empty(cap, dtype=np.uint8)
-    qual = np.empty(cap, dtype=np.uint8) if qs is not None else None
+    n1 = n2 = q_top = None
+    if qs is not None:
+        n1, n2, q_top = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.float64)
     n = C.c_int64()
-    _lib.check(_lib.load().chiron_consensus_device(int(device_id), bases.ctypes.data, off.ctypes.data, len(bpreads),
-                                                   None if qs is None else qs.ctypes.data, kid, cons.ctypes.data,
-                                                   None if qual is None else qual.ctypes.data, cap, C.byref(n)))
+    ptr = lambda a_: None if a_ is None else a_.ctypes.data
+    _lib.check(_lib.load().chiron_consensus_device(int(device_id), bases.ctypes.data, off.ctypes.data, len(bpreads), ptr(qs), kid,
+                                                   cons.ctypes.data, ptr(n1), ptr(n2), ptr(q_top), cap, C.byref(n)))
     seq = np.frombuffer(b"ACGT", dtype=np.uint8)[cons[:n.value]].tobytes().decode("ascii")
-    return seq, (None if qual is None else qual[:n.value].tobytes().decode("latin1"))
+    if qs is None:
+        return seq, None
+    from .eval import qs_from_votes
+    return seq, qs_from_votes(n1[:n.value].astype(np.float64), n2[:n.value].astype(np.float64), q_top[:n.value])

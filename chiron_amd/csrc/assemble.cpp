@@ -283,18 +283,22 @@ extern "C" chiron_status chiron_parse_signal_text(const char* text, size_t len, 
 // (BundleEntryProto.crc32c, masked; tensor_bundle.cc checks it on restore, chiron_amd/tf_bundle.py does the same).
 extern "C" chiron_status chiron_crc32c(const void* data, size_t len, uint32_t* out) {
   if ((!data && len) || !out) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_crc32c: null argument");
-  static uint32_t table[8][256];
-  static bool ready = false;
-  if (!ready) {   // idempotent: concurrent first calls write identical values
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
-      table[0][i] = c;
+  // built once: C++11 initialises a function-local static exactly once, with the stores ordered before any reader
+  // (ctypes releases the GIL, so first calls do race)
+  struct Table {
+    uint32_t t[8][256];
+    Table() {
+      for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+        t[0][i] = c;
+      }
+      for (int k = 1; k < 8; ++k)
+        for (uint32_t i = 0; i < 256; ++i) t[k][i] = t[0][t[k - 1][i] & 0xFF] ^ (t[k - 1][i] >> 8);
     }
-    for (int k = 1; k < 8; ++k)
-      for (uint32_t i = 0; i < 256; ++i) table[k][i] = table[0][table[k - 1][i] & 0xFF] ^ (table[k - 1][i] >> 8);
-    ready = true;
-  }
+  };
+  static const Table tab;
+  const uint32_t (*table)[256] = tab.t;
   const uint8_t* p = static_cast<const uint8_t*>(data);
   uint32_t crc = 0xFFFFFFFFu;
   while (len >= 8) {

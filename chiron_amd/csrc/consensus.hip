@@ -10,8 +10,11 @@
 //                         `continue` skips it)
 //   vote_kernel           one thread per consensus column: the segments covering it are found by bisection on the
 //                         (non-decreasing) starts, votes and quality sums accumulate in segment order, then the base
-//                         (first maximum, chiron_eval.py:457) and the Phred+33 character (qs()) are written directly;
-//                         no [4][len] matrices ever exist
+//                         (first maximum, chiron_eval.py:457) and the three numbers qs() needs of a column -- n1, n2 and
+//                         the quality sum behind the winning base -- are written; no [4][len] matrices ever exist.  The
+//                         Phred character itself is computed by the HOST's formula from those (eval.qs_from_votes): a
+//                         device log10 may differ from NumPy's in the last bit, and int() truncation turns that into a
+//                         different character at integer boundaries
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -96,7 +99,8 @@ __global__ __launch_bounds__(1024) void scan_starts_kernel(const int64_t* __rest
 
 __global__ __launch_bounds__(256) void vote_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ off, const int64_t* __restrict__ start,
                                                    const double* __restrict__ seg_qs, int64_t n_seg, int64_t length, int64_t maxn,
-                                                   uint8_t* __restrict__ consensus, uint8_t* __restrict__ quality) {
+                                                   uint8_t* __restrict__ consensus, int32_t* __restrict__ out_n1, int32_t* __restrict__ out_n2,
+                                                   double* __restrict__ out_qtop) {
   const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= length) return;
   // last segment whose start is <= col (starts are non-decreasing: every displacement is >= 0)
@@ -138,20 +142,24 @@ __global__ __launch_bounds__(256) void vote_kernel(const uint8_t* __restrict__ b
     }
   }
   consensus[col] = (uint8_t)arg;
-  if (quality) {
-    int q = 0;
-    if (n1 > 0) q = (int)(10.0 * log10((n1 + 1.0) / (n2 + 1.0)) + qsum[top] / n1 / log(10.0));
-    quality[col] = (uint8_t)(q + 33);
+  if (out_n1) {
+    out_n1[col] = (int32_t)n1;      // counts are small exact integers
+    out_n2[col] = (int32_t)n2;
+    out_qtop[col] = qsum[top];
   }
 }
 
+// Stream-ordered allocations: hipFree would synchronise the whole device and stall the engine's in-flight slots
 struct DeviceBuffers {
-  void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static constexpr int N = 10;
+  void* p[N] = {};
   hipStream_t stream = nullptr;
   ~DeviceBuffers() {
+    if (!stream) return;
     for (void* q : p)
-      if (q) hipFree(q);
-    if (stream) hipStreamDestroy(stream);
+      if (q) hipFreeAsync(q, stream);
+    hipStreamSynchronize(stream);
+    hipStreamDestroy(stream);
   }
 };
 
@@ -165,12 +173,15 @@ struct DeviceBuffers {
   } while (0)
 
 extern "C" chiron_status chiron_consensus_device(int32_t device_id, const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs,
-                                                 int32_t kernal, uint8_t* consensus, uint8_t* quality, int64_t cap, int64_t* out_len) {
+                                                 int32_t kernal, uint8_t* consensus, int32_t* n1, int32_t* n2, double* q_top, int64_t cap,
+                                                 int64_t* out_len) {
   using namespace chiron;
   if (!seg_off || !out_len || n_seg < 0) return set_error(CHIRON_ERR_INVALID, "chiron_consensus_device: bad arguments");
   if (kernal != CHIRON_KERNAL_GLUE && kernal != CHIRON_KERNAL_STICK)
     return set_error(CHIRON_ERR_INVALID, "chiron_consensus_device: kernal %d (1 = glue, 2 = stick; the simple kernel's displacements are host code)", kernal);
-  if (quality && !seg_qs) return set_error(CHIRON_ERR_INVALID, "chiron_consensus_device: quality requested without seg_qs");
+  const bool votes = n1 || n2 || q_top;
+  if (votes && !(n1 && n2 && q_top)) return set_error(CHIRON_ERR_INVALID, "chiron_consensus_device: n1, n2 and q_top come together");
+  if (votes && !seg_qs) return set_error(CHIRON_ERR_INVALID, "chiron_consensus_device: the vote summary was requested without seg_qs");
   *out_len = 0;
   if (n_seg < 2) return CHIRON_OK;   // a single segment yields an empty consensus (the reference's `continue`)
   const int64_t n_bases = seg_off[n_seg];
@@ -189,13 +200,15 @@ extern "C" chiron_status chiron_consensus_device(int32_t device_id, const uint8_
   int64_t*& d_len = reinterpret_cast<int64_t*&>(d.p[4]);
   double*& d_qs = reinterpret_cast<double*&>(d.p[5]);
   uint8_t*& d_cons = reinterpret_cast<uint8_t*&>(d.p[6]);
-  uint8_t*& d_qual = reinterpret_cast<uint8_t*&>(d.p[7]);
-  CONS_TRY(hipMalloc(&d.p[0], (size_t)n_bases + 16));
-  CONS_TRY(hipMalloc(&d.p[1], (size_t)(n_seg + 1) * 8));
-  CONS_TRY(hipMalloc(&d.p[2], (size_t)n_seg * 8));
-  CONS_TRY(hipMalloc(&d.p[3], (size_t)n_seg * 8));
-  CONS_TRY(hipMalloc(&d.p[4], 16));
-  if (seg_qs) CONS_TRY(hipMalloc(&d.p[5], (size_t)n_seg * 8));
+  int32_t*& d_n1 = reinterpret_cast<int32_t*&>(d.p[7]);
+  int32_t*& d_n2 = reinterpret_cast<int32_t*&>(d.p[8]);
+  double*& d_qtop = reinterpret_cast<double*&>(d.p[9]);
+  CONS_TRY(hipMallocAsync(&d.p[0], (size_t)n_bases + 16, d.stream));
+  CONS_TRY(hipMallocAsync(&d.p[1], (size_t)(n_seg + 1) * 8, d.stream));
+  CONS_TRY(hipMallocAsync(&d.p[2], (size_t)n_seg * 8, d.stream));
+  CONS_TRY(hipMallocAsync(&d.p[3], (size_t)n_seg * 8, d.stream));
+  CONS_TRY(hipMallocAsync(&d.p[4], 16, d.stream));
+  if (seg_qs) CONS_TRY(hipMallocAsync(&d.p[5], (size_t)n_seg * 8, d.stream));
   CONS_TRY(hipMemcpyAsync(d_bases, bases, (size_t)n_bases, hipMemcpyHostToDevice, d.stream));
   CONS_TRY(hipMemcpyAsync(d_off, seg_off, (size_t)(n_seg + 1) * 8, hipMemcpyHostToDevice, d.stream));
   if (seg_qs) CONS_TRY(hipMemcpyAsync(d_qs, seg_qs, (size_t)n_seg * 8, hipMemcpyHostToDevice, d.stream));
@@ -210,13 +223,21 @@ extern "C" chiron_status chiron_consensus_device(int32_t device_id, const uint8_
   if (length > cap) return set_error(CHIRON_ERR_OVERFLOW, "chiron_consensus_device: consensus needs %lld columns, capacity %lld", (long long)length, (long long)cap);
   if (length == 0) return CHIRON_OK;
   if (!consensus) return set_error(CHIRON_ERR_INVALID, "chiron_consensus_device: null consensus");
-  CONS_TRY(hipMalloc(&d.p[6], (size_t)length));
-  if (quality) CONS_TRY(hipMalloc(&d.p[7], (size_t)length));
+  CONS_TRY(hipMallocAsync(&d.p[6], (size_t)length, d.stream));
+  if (votes) {
+    CONS_TRY(hipMallocAsync(&d.p[7], (size_t)length * 4, d.stream));
+    CONS_TRY(hipMallocAsync(&d.p[8], (size_t)length * 4, d.stream));
+    CONS_TRY(hipMallocAsync(&d.p[9], (size_t)length * 8, d.stream));
+  }
   hipLaunchKernelGGL(vote_kernel, dim3((unsigned)((length + 255) / 256)), dim3(256), 0, d.stream, d_bases, d_off, d_start, seg_qs ? d_qs : nullptr,
-                     n_seg, length, len_maxn[1], d_cons, quality ? d_qual : nullptr);
+                     n_seg, length, len_maxn[1], d_cons, votes ? d_n1 : nullptr, votes ? d_n2 : nullptr, votes ? d_qtop : nullptr);
   CONS_TRY(hipGetLastError());
   CONS_TRY(hipMemcpyAsync(consensus, d_cons, (size_t)length, hipMemcpyDeviceToHost, d.stream));
-  if (quality) CONS_TRY(hipMemcpyAsync(quality, d_qual, (size_t)length, hipMemcpyDeviceToHost, d.stream));
+  if (votes) {
+    CONS_TRY(hipMemcpyAsync(n1, d_n1, (size_t)length * 4, hipMemcpyDeviceToHost, d.stream));
+    CONS_TRY(hipMemcpyAsync(n2, d_n2, (size_t)length * 4, hipMemcpyDeviceToHost, d.stream));
+    CONS_TRY(hipMemcpyAsync(q_top, d_qtop, (size_t)length * 8, hipMemcpyDeviceToHost, d.stream));
+  }
   CONS_TRY(hipStreamSynchronize(d.stream));
   return CHIRON_OK;
 }

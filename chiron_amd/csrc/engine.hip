@@ -1393,13 +1393,25 @@ extern "C" chiron_status chiron_engine_collect(chiron_engine* e, int32_t slot, c
   Slot* s = &e->slots[slot];
   if (s->state.v.load(std::memory_order_acquire) != 1) return fail(CHIRON_ERR_STATE, "collect on slot %d without a submitted batch", slot);
   HIP_TRY(hipSetDevice(e->opts.device_id));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  const int64_t nnz = s->h_meta[0];
-  if (!(s->flags & CHIRON_NO_DECODE_COPY) && nnz > 0) {
-    HIP_TRY(hipMemcpyAsync(s->h_indices, s->indices, (size_t)nnz * 16, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->h_values, s->values, (size_t)nnz * 8, hipMemcpyDeviceToHost, s->stream));
+  // A HIP error below loses the batch, not the slot: the stream is drained and the slot returns to idle, as a failed
+  // submit leaves it (otherwise every later submit would be refused with "still holds an uncollected batch").
+  auto drain = [&]() -> chiron_status {
     HIP_TRY(hipStreamSynchronize(s->stream));
+    const int64_t n = s->h_meta[0];
+    if (!(s->flags & CHIRON_NO_DECODE_COPY) && n > 0) {
+      HIP_TRY(hipMemcpyAsync(s->h_indices, s->indices, (size_t)n * 16, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipMemcpyAsync(s->h_values, s->values, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return CHIRON_OK;
+  };
+  const chiron_status dst = drain();
+  if (dst) {
+    hipStreamSynchronize(s->stream);
+    s->state.v.store(0, std::memory_order_release);
+    return dst;
   }
+  const int64_t nnz = s->h_meta[0];
   if (!(s->flags & CHIRON_WANT_PROB)) memset(s->h_prob, 0, (size_t)s->batch * 4);
   out->nnz = nnz;
   out->indices = s->h_indices;
@@ -1432,6 +1444,32 @@ extern "C" chiron_status chiron_engine_device_results(chiron_engine* e, int32_t 
   if (indices) *indices = s->indices;
   if (values) *values = s->values;
   if (nnz_and_shape) *nnz_and_shape = s->meta;
+  return CHIRON_OK;
+}
+
+// getcnnfeature (cnn.py:334-371): the [batch, T, C] feature tensor the CNN handed to the recurrent layers for the batch
+// most recently run on an idle slot.
+extern "C" chiron_status chiron_engine_features(chiron_engine* e, int32_t slot, float* out, size_t cap_floats, int32_t* out_batch,
+                                                int32_t* out_channels) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range", slot);
+  Slot* s = &e->slots[slot];
+  if (s->state.v.load(std::memory_order_acquire) != 0) return fail(CHIRON_ERR_STATE, "slot %d holds an uncollected batch", slot);
+  if (s->batch < 1 || s->sig_used == nullptr) return fail(CHIRON_ERR_STATE, "slot %d has not run a batch through the network", slot);
+  if (e->split) return fail(CHIRON_ERR_INVALID, "chiron_engine_features: dtype fp32-split keeps features as hi/lo half pairs; not exported");
+  const size_t n = (size_t)s->batch * e->T * e->C;
+  if (out_batch) *out_batch = s->batch;
+  if (out_channels) *out_channels = e->C;
+  if (!out || cap_floats < n) return fail(CHIRON_ERR_OVERFLOW, "features need %zu floats, capacity %zu", n, cap_floats);
+  HIP_TRY(hipSetDevice(e->opts.device_id));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (e->f16) {
+    std::vector<_Float16> h(n);
+    HIP_TRY(hipMemcpy(h.data(), s->sig_used, n * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) out[i] = (float)h[i];
+  } else {
+    HIP_TRY(hipMemcpy(out, s->sig_used, n * 4, hipMemcpyDeviceToHost));
+  }
   return CHIRON_OK;
 }
 

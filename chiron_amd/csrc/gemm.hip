@@ -987,13 +987,7 @@ bool launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int nblocks_n = (p.N + GEMM_BN - 1) / GEMM_BN;
   const int mblocks = (p.M + GEMM_BM - 1) / GEMM_BM;
   const int total_ids = ((mblocks + 7) / 8) * 8 * nblocks_n;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = current_device_cus();
   int g = 2 * n_cu;            // two resident workgroups per CU (69 KB LDS each; 77 KB for the projection layout)
   g = (g / 8) * 8;
   if (g > total_ids) g = total_ids;

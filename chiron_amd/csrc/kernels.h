@@ -8,6 +8,28 @@
 
 namespace chiron {
 
+// Per-device launch facts.  One process may hold engines on several devices (include/chiron_amd.h: engines on different
+// devices are independent), so nothing a launcher caches may be process-wide: the CU count and the "dynamic LDS opt-in
+// done" flags are indexed by the current device.
+constexpr int CHIRON_MAX_DEVICES = 64;
+inline int current_device_index() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CHIRON_MAX_DEVICES) dev = 0;
+  return dev;
+}
+inline int current_device_cus() {
+  static int n_cu[CHIRON_MAX_DEVICES] = {};   // racing first calls store the same value
+  const int dev = current_device_index();
+  int n = __atomic_load_n(&n_cu[dev], __ATOMIC_RELAXED);
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    if (n <= 0) n = 256;
+    __atomic_store_n(&n_cu[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused conv / projection GEMM on v_mfma_f32_32x32x2_f32  (gemm.hip)
 //

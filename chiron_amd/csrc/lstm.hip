@@ -829,16 +829,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     }
 }
 
-static int lstm_cu_count() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  return n_cu;
-}
+static int lstm_cu_count() { return current_device_cus(); }
 
 void launch_lstm(const LstmParams& p0, hipStream_t stream) {
   // hidden = 100 is the only size the reference's shipped models use (rnn.py:23 hidden_num=100)

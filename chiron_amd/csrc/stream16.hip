@@ -292,19 +292,19 @@ bool launch_stream16(const GemmParams& p, hipStream_t stream) {
     if (s.shift != (taps ? i - 1 : 0) || (taps && (s.src != p.seg[0].src || s.lda != p.seg[0].lda || s.col0 != p.seg[0].col0))) return false;
     if ((size_t)p.M * (size_t)s.lda * 2 > S_RECORDS) return false;
   }
-  static int n_cu = 0;
-  static bool attr_ok = false;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 1 * S_TILE_H * 2) == hipSuccess &&
+  const int n_cu = current_device_cus();
+  static char attr_state[CHIRON_MAX_DEVICES] = {};   // 0 unknown, 1 opted in, 2 refused -- per device
+  const int dev = current_device_index();
+  char st = __atomic_load_n(&attr_state[dev], __ATOMIC_ACQUIRE);
+  if (st == 0) {
+    const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 1 * S_TILE_H * 2) == hipSuccess &&
               hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * S_TILE_H * 2) == hipSuccess &&
               hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_f16_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S3_D * S3_TILE_H * 2) == hipSuccess;
     if (!attr_ok) (void)hipGetLastError();   // not sticky: the caller falls back to gemm.hip
+    st = attr_ok ? 1 : 2;
+    __atomic_store_n(&attr_state[dev], st, __ATOMIC_RELEASE);
   }
-  if (!attr_ok) return false;
+  if (st != 1) return false;
   const int ntiles = (p.M + S_ROWS - 1) / S_ROWS;
   if (ntiles <= 0) return true;   // nothing to do
   const int grid = std::min(n_cu, ntiles);

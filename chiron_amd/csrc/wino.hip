@@ -465,18 +465,13 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
 bool launch_wino_conv3(const WinoParams& p, hipStream_t stream) {
   if (p.T <= 0 || (p.T & 1) || p.C <= 0 || (p.C % WK) || p.N <= 0 || (p.N % WN) || p.N > 1024) return false;
   if ((size_t)p.B * p.T * (size_t)p.lda * 4 > RECORDS) return false;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
+  const int n_cu = current_device_cus();
+  static char attr_set[CHIRON_MAX_DEVICES] = {};   // the dynamic-LDS opt-in is a per-device function attribute
+  const int dev = current_device_index();
+  if (!__atomic_load_n(&attr_set[dev], __ATOMIC_ACQUIRE)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv3_f4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
-    attr_set = true;
+    __atomic_store_n(&attr_set[dev], (char)1, __ATOMIC_RELEASE);
   }
   int g = (n_cu / 8) * 8;
   if (p.f4) {   // F(4,3): U holds six transformed filters, T is a multiple of 4

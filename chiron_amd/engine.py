@@ -109,8 +109,9 @@ class Engine(object):
             flags |= _lib.WANT_LOGITS
         if not copy_decoded:
             flags |= _lib.NO_DECODE_COPY
-        self._keep[slot] = (x, seq_len)
+        # A submit refused with ERR_STATE leaves the slot's in-flight batch untouched: its keep-alive must survive
         _lib.check(self._lib.chiron_engine_submit(self._h, slot, xp, sp, batch, int(beam_width), flags))
+        self._keep[slot] = (x, seq_len)
 
     def collect(self, slot):
         """Blocks; returns DecodeResult with numpy copies (valid indefinitely)."""
@@ -141,11 +142,21 @@ class Engine(object):
         if logits.ndim != 3 or logits.shape[1] != self.T or logits.shape[2] != self.spec.classes:
             raise ValueError("logits must be [batch, %d, %d]" % (self.T, self.spec.classes))
         flags = _lib.WANT_PROB if want_prob else 0
-        self._keep[slot] = (logits, seq_len)
         _lib.check(self._lib.chiron_engine_decode(self._h, slot, logits.ctypes.data_as(C.c_void_p),
                                                   seq_len.ctypes.data_as(C.c_void_p), logits.shape[0],
                                                   int(beam_width), flags))
+        self._keep[slot] = (logits, seq_len)
         return self.collect(slot)
+
+    def features(self, slot=0):
+        """getcnnfeature (cnn.py:334-371): the CNN feature tensor [batch, T, C] of the batch last run on the (idle) slot."""
+        b, c = C.c_int32(), C.c_int32()
+        st = self._lib.chiron_engine_features(self._h, slot, None, 0, C.byref(b), C.byref(c))
+        if st != _lib.ERR_OVERFLOW:
+            _lib.check(st)
+        out = np.empty((b.value, self.T, c.value), dtype=np.float32)
+        _lib.check(self._lib.chiron_engine_features(self._h, slot, out.ctypes.data_as(C.c_void_p), out.size, C.byref(b), C.byref(c)))
+        return out
 
     def sync(self):
         _lib.check(self._lib.chiron_engine_sync(self._h))

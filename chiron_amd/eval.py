@@ -116,6 +116,16 @@ def qs(consensus, consensus_qs, output_standard="phred+33"):
     np.put_along_axis(rest, top[None, :], -1.0, axis=0)
     n2 = rest.max(axis=0)
     q_top = np.take_along_axis(np.asarray(consensus_qs, dtype=np.float64), top[None, :], axis=0)[0]
+    return qs_from_votes(n1, n2, q_top, output_standard)
+
+
+def qs_from_votes(n1, n2, q_top, output_standard="phred+33"):
+    """The formula of qs() on a column's vote summary (float64 arrays): n1 >= n2 the two largest counts, q_top the quality
+    sum behind the winning base.  Shared by the host vote (qs) and the device vote (assembly.consensus_device), so both
+    produce the same characters whatever log10 the device has."""
+    n_col = n1.shape[0]
+    if n_col == 0:
+        return np.zeros(0, dtype=int) if output_standard == "number" else ""
     voted = n1 > 0
     if voted.all():
         score = 10 * np.log10((n1 + 1) / (n2 + 1)) + q_top / n1 / np.log(10)
@@ -129,7 +139,7 @@ def qs(consensus, consensus_qs, output_standard="phred+33"):
         codes = score + 33
         if codes.min() >= 0 and codes.max() < 128:      # every realistic score: one ASCII byte per column
             return codes.astype(np.uint8).tobytes().decode("ascii")
-        return "".join(map(chr, codes))
+        return "".join(map(chr, codes))                 # as the reference: chr() of a large code, ValueError for a negative one
     raise ValueError("output_standard must be 'number' or 'phred+33'")
 
 
@@ -359,6 +369,7 @@ def _finish_read_in_process(name, flat, seg_len, qs_list, flags, t_start, readin
     import argparse
     ends = np.cumsum(seg_len)
     reads = [flat[e - n:e] for e, n in zip(ends.tolist(), seg_len.tolist())]
+    flags = dict(flags, device_vote_min_segments=1 << 62)     # host vote only: a worker process must not open the GPU
     return finish_read(name, reads, qs_list, argparse.Namespace(**flags), t_start, reading_time)
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CHIRON_ABI_VERSION 3
+#define CHIRON_ABI_VERSION 4
 #define CHIRON_MAX_BLOCKS 8
 #define CHIRON_CLASSES 5 /* A,C,G,T,blank (rnn.py:25 class_n=5) */
 
@@ -196,6 +196,14 @@ chiron_status chiron_engine_device_results(chiron_engine* e, int32_t slot, const
                                            const int64_t** indices, const int64_t** values,
                                            const int64_t** nnz_and_shape /* [3]: nnz,batch,maxlen */);
 
+/* getcnnfeature (cnn.py:334-371): the CNN feature tensor [batch, T, C] (float32; an f16 engine's halves are widened)
+ * of the batch most recently run on `slot`, which must be idle (collected).  Copied into out [cap_floats];
+ * *out_batch / *out_channels receive batch and C.  CHIRON_ERR_OVERFLOW when cap_floats is too small (the sizes are
+ * still reported), CHIRON_ERR_STATE before the first batch or with a batch in flight.  Stage-level parity checks use
+ * it (tests); dtype CHIRON_F32_SPLIT does not export its hi/lo pairs (CHIRON_ERR_INVALID).                       */
+chiron_status chiron_engine_features(chiron_engine* e, int32_t slot, float* out, size_t cap_floats, int32_t* out_batch,
+                                     int32_t* out_channels);
+
 /* Per-kernel timing with HIP events on the engine's own streams (bench.py
  * roofline).  Enable, run, sync, then read.                                    */
 typedef struct {
@@ -235,14 +243,19 @@ chiron_status chiron_overlap_displacement(const uint8_t* cur, int64_t n, const u
 
 /* The same consensus on the device, for one read (very long reads): glue / stick displacements of every
  * consecutive segment pair, running start columns, the vote, and per consensus column the winning base
- * (np.argmax(consensus, axis=0), chiron_eval.py:457: first maximum) and, when seg_qs is given, its Phred+33 character
- * (qs(), chiron_eval.py:152-174) -- i.e. chiron_assemble + argmax + qs without the [4][len] matrices ever leaving the
- * GPU.  Host pointers in and out; the call owns a stream and its device buffers (thread-safe, independent of any
- * engine).  consensus [cap] receives 0..3, quality [cap] (may be NULL) the characters; *out_len the length;
- * CHIRON_ERR_OVERFLOW if cap is too small (then *out_len = needed).  kernal: CHIRON_KERNAL_GLUE or _STICK.        */
+ * (np.argmax(consensus, axis=0), chiron_eval.py:457: first maximum) and, when seg_qs is given, the three numbers
+ * qs() (chiron_eval.py:152-174) reads of a column: n1 and n2, the two largest vote counts, and q_top, the summed segment
+ * quality behind the winning base (the last of equal maxima) -- i.e. chiron_assemble + argmax + the inputs of qs without
+ * the [4][len] matrices ever leaving the GPU.  All of it is integer work or ordered double sums: identical to the host
+ * vote.  The Phred character q = int(10 log10((n1+1)/(n2+1)) + q_top/n1/ln 10) is left to the caller's own formula
+ * (chiron_amd.eval.qs_from_votes), because truncation turns a last-bit difference between two log10 implementations
+ * into a different character.  Host pointers in and out; the call owns a stream and stream-ordered device buffers
+ * (thread-safe, independent of any engine, no device-wide synchronisation).  consensus [cap] receives 0..3; n1, n2
+ * [cap] int32 and q_top [cap] float64 come together or are all NULL; *out_len the length; CHIRON_ERR_OVERFLOW if cap is
+ * too small (then *out_len = needed).  kernal: CHIRON_KERNAL_GLUE or _STICK.                                       */
 chiron_status chiron_consensus_device(int32_t device_id, const uint8_t* bases, const int64_t* seg_off, int64_t n_seg,
-                                      const double* seg_qs, int32_t kernal, uint8_t* consensus, uint8_t* quality,
-                                      int64_t cap, int64_t* out_len);
+                                      const double* seg_qs, int32_t kernal, uint8_t* consensus, int32_t* n1, int32_t* n2,
+                                      double* q_top, int64_t cap, int64_t* out_len);
 
 /* Host-side reader of the reference's raw-signal text format: chiron_input.py:527-539 read_signal() --
  * `f.read().split()` converted to float32 -- whitespace/newline separated numbers.  Each token is parsed as a

@@ -1,0 +1,87 @@
+"""Weight regimes for the parity tests (test infrastructure; uses the float64 oracle to calibrate BN statistics).
+
+ca.synthetic_weights keeps every BN site near N(0, 1) and the LSTM gates in their linear region -- convenient, and not what
+a trained checkpoint looks like.  Two families are built here on top of it:
+
+* saturated_gate_cases: gate biases of +-50 .. +-120 (cell written through / closed / integrating without output / held and
+  output) and a 1e-3 kernel gain (every gate at its midpoint): rnn.py:45-65 LSTMCell, SURVEY A.2.
+* trained_like_weights: convolution filters with heterogeneous input-channel scales (log-normal, two decades) and a non-zero
+  mean per output channel, BN scale in +-[0.3, 3] and offsets of order 1 (post-BN activations reach +-10 and beyond), population
+  statistics CALIBRATED on data the way training's moving averages are (the float64 oracle walks the network and records every
+  site's moments -- so conv outputs have large means that the folded BN shift cancels, the case where a re-associated
+  convolution such as Winograd F(4,3) with its x8 and /24 constants loses most), LSTM gate biases spread over several units
+  so that a good share of the gates saturates per step while the dynamics stay contracting.
+"""
+import numpy as np
+
+import chiron_amd as ca
+
+H = 100
+
+SATURATED = {"write-through": (50.0, -50.0, 50.0), "closed": (-50.0, -50.0, -50.0), "integrate-no-output": (120.0, 80.0, -90.0),
+             "hold-and-output": (-50.0, 50.0, 50.0), "midpoint": "tiny"}
+
+
+def saturated_gate_weights(spec, name, seed=9):
+    """(i, f, o) biases.  All three open at once is left out on purpose: the cell then integrates hundreds of steps of +-1 through
+    a recurrent loop of gain ~1 and fp32 / fp64 restatements of the SAME formulas drift apart by 0.5 (numpy oracle at both
+    precisions): sensitivity of the network, not of an implementation."""
+    gates = SATURATED[name]
+    if gates == "tiny":
+        return ca.synthetic_weights(spec, seed=seed, lstm_gain=1e-3)
+    w = ca.synthetic_weights(spec, seed=seed)
+    h = spec.hidden
+    for k in w:
+        if k.endswith("lstm_cell/bias"):
+            b = w[k]                     # columns i | j | f | o
+            b[0:h], b[2 * h:3 * h], b[3 * h:4 * h] = gates
+    return w
+
+
+def trained_like_weights(spec, x_calib, seed=5, lstm_gain=3.0, gate_spread=3.0, chan_sigma=1.0):
+    from oracle import nn_oracle
+    w = ca.synthetic_weights(spec, seed=seed, lstm_gain=lstm_gain)
+    rng = np.random.RandomState(seed + 1000)
+    for k in list(w):
+        a = w[k]
+        if k.endswith("/weights") and a.ndim == 4:
+            _, kk, cin, cout = a.shape
+            if cin > 1:
+                a = a * np.exp(rng.normal(0.0, chan_sigma, (1, 1, cin, 1)))
+                if "/branch1/" not in k:           # the shortcut of blocks 2, 3 has no BN behind it: leave its mean alone
+                    a = a + rng.normal(0.0, 0.6 / np.sqrt(kk * cin), (1, 1, 1, cout))
+                else:
+                    a = a * np.exp(-0.5 * chan_sigma * chan_sigma) * 0.5
+            w[k] = a.astype(np.float32)
+        elif k.endswith("_bn/scale"):
+            w[k] = (rng.uniform(0.3, 3.0, a.shape) * rng.choice([-1.0, 1.0], a.shape, p=[0.15, 0.85])).astype(np.float32)
+        elif k.endswith("_bn/offset"):
+            w[k] = rng.normal(0.0, 1.0, a.shape).astype(np.float32)
+        elif k.endswith("lstm_cell/bias"):
+            h = spec.hidden
+            b = np.empty(4 * h)
+            b[0:h] = rng.normal(0.0, gate_spread, h)           # i
+            b[h:2 * h] = rng.normal(0.0, 0.5, h)               # j
+            b[2 * h:3 * h] = rng.normal(1.0, gate_spread, h)   # f (+1.0 forget bias on top)
+            b[3 * h:4 * h] = rng.normal(0.0, gate_spread, h)   # o
+            w[k] = b.astype(np.float32)
+    # population statistics = the moments the data really has at each site (float64 walk, upstream sites already calibrated)
+    orig = nn_oracle.bn_site
+
+    def calibrating(xx, weights, site, mode):
+        weights[site + "_bn/pop_mean"] = xx.mean(axis=(0, 1)).astype(np.float32)
+        weights[site + "_bn/pop_var"] = xx.var(axis=(0, 1)).astype(np.float32)
+        return orig(xx, weights, site, "population")
+
+    nn_oracle.bn_site = calibrating
+    try:
+        fea = nn_oracle.cnn_forward(np.asarray(x_calib, dtype=np.float64), spec.to_dict(), w)
+    finally:
+        nn_oracle.bn_site = orig
+    # the LSTM sees features of order 1 in synthetic_weights; keep its input projection in the same range
+    s = float(np.sqrt((fea ** 2).mean()))
+    for k in w:
+        if k.endswith("lstm_cell/kernel") and ("cell_0" in k):
+            nin = w[k].shape[0] - spec.hidden
+            w[k][:nin] = (w[k][:nin] / max(s, 1e-6) * 0.75).astype(np.float32)
+    return w, fea

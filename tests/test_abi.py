@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == bound, "binding and header disagree: %s" % (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.chiron_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.chiron_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_weights_size_and_validation(built):

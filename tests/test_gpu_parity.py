@@ -419,6 +419,146 @@ def test_winograd_conv2b_against_direct_form_and_oracle(dna, rna, monkeypatch):
             assert np.abs(outs[mode] - ref).max() < TOL, mode
 
 
+def _engine_variants(monkeypatch):
+    """(name, dtype, env) of every recurrence / convolution form the regimes are driven through.  The f16 forms are held to
+    the fp32 ENGINE (the f16 bound of test_f16_path_tolerance_vs_f32), the fp32 forms to the float64 oracle."""
+    return (("fp32", "fp32", {}), ("fp32-paired", "fp32", {"CHIRON_LSTM_PAIR": "1"}), ("fp32-split", "fp32-split", {}),
+            ("fp16-fused", "fp16", {"CHIRON_LSTM16_FUSED_MIN": "1"}), ("fp16-unfused", "fp16", {"CHIRON_LSTM16_UNFUSED": "1"}),
+            ("fp16-narrow", "fp16", {"CHIRON_LSTM16_NARROW": "1"}))
+
+
+_REGIME_ENV = ("CHIRON_LSTM_PAIR", "CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED", "CHIRON_LSTM16_NARROW", "CHIRON_NO_WINOGRAD",
+               "CHIRON_WINOGRAD_F2")
+
+
+def _run_variant(monkeypatch, spec, w, x, ln, L, dtype, env, features=False):
+    for v in _REGIME_ENV:
+        monkeypatch.delenv(v, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    try:
+        with ca.Engine(spec, w, max_batch=x.shape[0], segment_len=L, dtype=dtype) as eng:
+            sl = ca.seq_len_for_engine(ln, eng.ratio)
+            res = eng.infer(x, sl, want_logits=True)
+            fea = eng.features() if features else None
+    finally:
+        for v in _REGIME_ENV:
+            monkeypatch.delenv(v, raising=False)
+    return res.logits, sl, fea
+
+
+@pytest.mark.parametrize("topology", ["dna", "rna"])
+def test_saturated_gates_and_extreme_preactivations(dna, rna, monkeypatch, topology):
+    """The recurrence evaluates sigmoid / tanh on the hardware exp2 / rcp (lstm.hip lstm_cell) instead of libm's expf /
+    tanhf.  With the default synthetic weights the gates live in their linear region; trained models do not.  Gate biases
+    of +-50 .. +-120 saturate the sigmoids completely -- 2^(+-170) and inf / 0 intermediates inside the formulas must
+    still give exactly 0 and 1 -- with the cell written through, frozen, integrating without output, or held; a tiny
+    kernel gain puts every gate at its midpoint (rnn.py:45-65 LSTMCell).  Every recurrence form of the engine
+    is driven through every case: fp32 (7-wave and paired workgroups) and fp32-split against the float64 oracle at 1e-4;
+    fp16 fused / unfused 16-row / 4-row against the fp32 engine at the f16 bound; DNA (stacked BiLSTM) and RNA (MultiRNN)."""
+    import regimes
+    from oracle import nn_oracle
+    spec, _ = dna if topology == "dna" else rna
+    L, jump, B = (400, 390, 20) if topology == "dna" else (500, 490, 20)
+    x, ln = _windows(jump * (B - 1) + 200, L, jump, seed=61)
+    ln = ln.copy()
+    ln[3], ln[7] = L // 3, 0
+    report = {}
+    for name in regimes.SATURATED:
+        w = regimes.saturated_gate_weights(spec, name)
+        ref = None
+        got32 = None
+        for vname, dtype, env in _engine_variants(monkeypatch):
+            got, sl, _ = _run_variant(monkeypatch, spec, w, x, ln, L, dtype, env)
+            assert np.isfinite(got).all(), (name, vname)
+            if ref is None:
+                ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+            if dtype == "fp16":
+                mask = (np.arange(got.shape[1])[None, :] < sl[:, None])[..., None]
+                err = (np.abs(got - got32) * mask).max()
+                assert err < 0.08, (name, vname, err)
+            else:
+                err = np.abs(got - ref).max()
+                assert err < TOL, (name, vname, err)
+                if vname == "fp32":
+                    got32 = got
+            report["%s/%s" % (name, vname)] = float(err)
+    _dump_report("saturated_gates_%s" % topology, report)
+
+
+def _dump_report(name, report):
+    """Measured deviations next to the run (gpurun_out/ is scratch; DESIGN quotes them)."""
+    import json
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_%s.json" % name), "w") as fh:
+            json.dump(report, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("case", ["dna-f4", "rna-f4", "dna-f2"])
+def test_trained_like_weights_through_every_conv_form(dna, rna, monkeypatch, case):
+    """Trained-checkpoint-like regime (tests/regimes.py): filters with input-channel scales over two decades and non-zero
+    means, BN scales in +-[0.3, 3] with offsets of order 1, population statistics calibrated on data (conv outputs with large
+    means that the folded shift cancels), LSTM gate biases spread over several units so that gates saturate.
+    Stage 1 -- getcnnfeature: the engine's CNN features (Winograd F(4,3) / F(2,3) / direct conv2b, table form of block 1)
+    against the float64 oracle, relative to the feature scale; the re-associated forms may not lose more than 4x what the
+    direct form loses.  Stage 2 -- logits of every recurrence form.  The recurrent stack amplifies what it is fed (the
+    float32 numpy restatement of the SAME formulas deviates from float64 by more than 1e-4 for some of these weights), so
+    the bound on logits is 1e-4 or 4x the float32 restatement's own deviation, whichever is larger; the measured figures
+    are written to gpurun_out/parity_trained_like_*.json."""
+    import regimes
+    from oracle import nn_oracle
+    spec, L, jump = {"dna-f4": (dna[0], 400, 390), "rna-f4": (rna[0], 500, 490), "dna-f2": (dna[0], 398, 390)}[case]
+    B = 24
+    x, ln = _windows(jump * (B - 1) + 200, L, jump, seed=67)
+    ln = ln.copy()
+    ln[2], ln[5] = L // 3, 0
+    w, _ = regimes.trained_like_weights(spec, x, seed=5)
+    sd = spec.to_dict()
+    report = {}
+    fea64 = nn_oracle.cnn_forward(x.astype(np.float64), sd, w)
+    fea32 = nn_oracle.cnn_forward(x.astype(np.float32), sd, {k: v.astype(np.float32) for k, v in w.items()})
+    scale = float(np.abs(fea64).max())
+    report["feature_max"] = scale
+    report["feature_rms"] = float(np.sqrt((fea64 ** 2).mean()))
+    report["features/numpy-fp32"] = float(np.abs(fea32 - fea64).max())
+    errs = {}
+    for form, env in (("default", {}), ("f2", {"CHIRON_WINOGRAD_F2": "1"}), ("direct", {"CHIRON_NO_WINOGRAD": "1"})):
+        got, sl, fea = _run_variant(monkeypatch, spec, w, x, ln, L, "fp32", env, features=True)
+        errs[form] = float(np.abs(fea - fea64).max())
+        report["features/" + form] = errs[form]
+        assert np.isfinite(fea).all()
+    # features: absolute bound relative to their scale (fp32 has 2^-24 per operation; K = 768 products per output, BN shift
+    # cancelling conv outputs several times larger than the result)
+    for form, e_ in errs.items():
+        assert e_ < 2e-5 * max(scale, 1.0), (form, e_, scale)
+        assert e_ < 4 * max(errs["direct"], report["features/numpy-fp32"]), (form, errs)
+    ref, _ = nn_oracle.inference(x, sl, sd, w, dtype=np.float64)
+    r32, _ = nn_oracle.inference(x, sl, sd, w, dtype=np.float32)
+    own = float(np.abs(r32 - ref).max())
+    report["logits/numpy-fp32"] = own
+    bound = max(TOL, 4 * own)
+    got32 = None
+    for vname, dtype, env in _engine_variants(monkeypatch):
+        got, sl, _ = _run_variant(monkeypatch, spec, w, x, ln, L, dtype, env)
+        assert np.isfinite(got).all(), vname
+        if dtype == "fp16":
+            mask = (np.arange(got.shape[1])[None, :] < sl[:, None])[..., None]
+            err = float((np.abs(got - got32) * mask).max())
+            report["logits/%s-vs-fp32-engine" % vname] = err
+            assert err < 0.25, (vname, err)
+        else:
+            err = float(np.abs(got - ref).max())
+            report["logits/" + vname] = err
+            assert err < bound, (vname, err, own)
+            if vname == "fp32":
+                got32 = got
+    _dump_report("trained_like_%s" % case, report)
+
+
 def _beam_rows(res, B):
     got = [[] for _ in range(B)]
     for (r, _), v in zip(res.decoded.indices, res.decoded.values):

@@ -153,6 +153,33 @@ def _assert_qs_matches_reference(cons, cqs, ref_string):
     return len(tied)
 
 
+def test_qs_ties_follow_the_stable_argsort_of_the_references_numpy():
+    """Q16: chiron_eval.py:165-170 reads count and quality sum at position 3 of np.argsort(consensus, axis=0).  Among EQUAL top
+    counts the base that lands there depends on the sort: NumPy 1.x (the reference's era) sorts four elements with an
+    insertion sort, i.e. stably -- the highest base index is last; NumPy 2's SIMD sorting network on this container's CPU is
+    not stable.  The product pins the stable rule (eval.qs, consensus.hip).  The formula below is the reference's, restated
+    with kind='stable'; matrices are built to contain two-, three- and four-way ties at the top and at the second rank."""
+    from chiron_amd import eval as ev
+    rng = np.random.RandomState(11)
+    for trial in range(300):
+        n = rng.randint(1, 40)
+        counts = rng.randint(0, 4, size=(4, n)).astype(np.float64)          # small range: ties in most columns
+        counts[rng.randint(0, 4), :] += 1.0                                  # no all-zero column (Q15 is tested on its own)
+        if trial % 3 == 0:
+            counts[:, : n // 2] = counts[0:1, : n // 2] + 1.0                # four-way ties, never all zero
+        q_sum = np.round(rng.uniform(0, 9, size=(4, n)) * counts, 3)
+        sort_ind = np.argsort(counts, axis=0, kind="stable")
+        cols = np.arange(n)[np.newaxis, :]
+        sc, sq = counts[sort_ind, cols], q_sum[sort_ind, cols]
+        want = (10 * np.log10((sc[3] + 1) / (sc[2] + 1)) + sq[3] / sc[3] / np.log(10)).astype(int)
+        assert np.array_equal(ev.qs(counts, q_sum, "number"), want), trial
+        assert ev.qs(counts, q_sum) == "".join(chr(v + 33) for v in want)
+    # and the shared formula on a vote summary (the device vote's path) gives the same characters
+    counts = np.array([[3., 3., 0.], [3., 1., 2.], [0., 3., 2.], [1., 0., 2.]])
+    q_sum = np.array([[9., 6., 0.], [7.5, 1., 4.], [0., 5.25, 4.5], [1., 0., 5.]])
+    assert ev.qs(counts, q_sum) == ev.qs_from_votes(np.array([3., 3., 2.]), np.array([3., 3., 2.]), np.array([7.5, 5.25, 5.]))
+
+
 def test_qs_zero_vote_column_and_shapes():
     """a column with no votes (n1 = 0) makes the reference divide 0 by 0 and chr() a garbage int
     (chiron_eval.py:168-169); decision: such a column scores 0 ('!') and the rest of the read is unaffected."""
