@@ -116,6 +116,9 @@ extern "C" chiron_status chiron_weights_size(const chiron_model_desc* d, size_t*
 // ----------------------------------------------------------------------------------------------
 // engine state
 // ----------------------------------------------------------------------------------------------
+// Default form of the fp32 recurrence (DESIGN 3.2 has the same-box A/B figures behind the choice)
+#define CHIRON_LSTM_WIDE_DEFAULT 0
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -156,6 +159,7 @@ struct LstmPlan {
   void* whfused = nullptr;  // f16: W_hh in the 16x16x32 order of lstm16f_kernel
   void* wxwide = nullptr;   // f16: input weights in that order (lstm16f_kernel: projection fused into the recurrence)
   int wx_ksteps = 0;        //      its k-steps of 16 (16: K = 256, 13: K = 200)
+  float* wwide32 = nullptr; // fp32: recurrent weights in the 16x16x4 B-operand order of lstm32w_kernel
   float* wlight = nullptr;  // K-split fragment of units 96..99 for the paired recurrence (fp32, H = 100)
 };
 
@@ -222,6 +226,7 @@ struct chiron_engine {
   bool lstm16_fused = false;      // f16: x-projection inside the recurrence (whole 16-row groups that fill the CUs)
   bool lstm16_narrow = false;     // A/B switch: f16 recurrence on 4-row workgroups only
   bool lstm_fixed_roles = false;  // A/B switch: light role always on wave 6
+  bool lstm_narrow = false;       // A/B switch: fp32 recurrence on the 4-row kernels (lstm_kernel) instead of lstm32w_kernel
   bool lstm_paired = false;  // fp32 recurrence: 14-wave workgroups for the part of a batch that fits one resident round
   bool bn_batch = false;  // desc.bn_mode == CHIRON_BN_BATCH
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
@@ -653,6 +658,19 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
             if (k < H) wl[((size_t)dir * 28 + m) * 64 + lane] = kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + 96 + j];
           }
       if ((st = dev_upload(e, &lp.wlight, wl))) return st;
+      if (H == 100) {
+        // lstm32w_kernel: [dir][wave 8][slot 4][k-step 25][lane]; lane = kq*16 + 4u + gate, tile = 3 wave + slot
+        std::vector<float> ww((size_t)2 * 8 * 4 * 25 * 64, 0.f);
+        for (int dir = 0; dir < 2; ++dir)
+          for (int wv = 0; wv < 8; ++wv)
+            for (int slot = 0; slot < (wv == 7 ? 4 : 3); ++slot)
+              for (int ks = 0; ks < 25; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                  const int k = 4 * ks + (lane >> 4), g = lane & 3, unit = 4 * (3 * wv + slot) + ((lane >> 2) & 3);
+                  ww[((((size_t)dir * 8 + wv) * 4 + slot) * 25 + ks) * 64 + lane] = kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + unit];
+                }
+        if ((st = dev_upload(e, &lp.wwide32, ww))) return st;
+      }
     }
     e->lstm.push_back(lp);
   }
@@ -820,6 +838,11 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   // with another slot's GEMM workgroups, gives the higher throughput (3905 vs 4004 kbases/s on one box).
   e->lstm_paired = getenv("CHIRON_LSTM_PAIR") != nullptr;
   e->lstm_fixed_roles = getenv("CHIRON_LSTM_FIXED_ROLES") != nullptr;
+  // fp32 recurrence form: CHIRON_LSTM_WIDE=1 -> lstm32w_kernel (16 rows per workgroup), =0 -> lstm_kernel (4 rows); read once here
+  {
+    const char* wv = getenv("CHIRON_LSTM_WIDE");
+    e->lstm_narrow = wv ? atoi(wv) == 0 : !CHIRON_LSTM_WIDE_DEFAULT;
+  }
   e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;
   e->lstm16_pair = getenv("CHIRON_LSTM16_PAIR") != nullptr;
   e->stream16 = getenv("CHIRON_NO_STREAM16") == nullptr;
@@ -1184,6 +1207,8 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.wfrag = lp.wfrag;
     r.wlight = lp.wlight;
     r.wwide = lp.wwide;
+    r.wwide32 = lp.wwide32;
+    r.narrow32 = e->lstm_narrow ? 1 : 0;
     r.narrow16 = e->lstm16_narrow ? 1 : 0;
     r.xsrc = nullptr;
     r.wxwide = nullptr;

@@ -124,6 +124,9 @@ struct LstmParams {
   const float* wfrag;    // [ndir][LSTM_NW][LSTM_K][64 lanes] recurrent weights, fragment order
   const float* wlight;   // [ndir][28][64 lanes] units 96..99 in the K-split order of the light wave (fp32 kernel):
                          //   entry m = 4q + a, lane = kg*16 + gate*4 + j  ->  W_hh[k = 16q + 4kg + a][gate*H + 96 + j]
+  const float* wwide32;  // fp32 wide form (lstm32w_kernel): [ndir][8 waves][4 tile slots][25 k-steps][64 lanes], lane = kq*16 + 4u + gate ->
+                         //   W_hh[k = 4 ks + kq][gate*H + 4 tile + u], tile = 3 wave + slot (zero for the slots a wave does not use)
+  int narrow32;          // fp32: 1 = the 4-row kernels (lstm_kernel) instead of the wide form (CHIRON_LSTM_WIDE=0)
   const void* wwide;     // f16 wide form: [ndir][8 waves][4 tile slots][7 k-steps][64 lanes][4 halves], lane = kq*16 + 4u + gate ->
                          //   W_hh[k = 16 ks + 4 kq + e][gate*H + 4 tile + u], tile = 3 wave + slot (zero past K or the wave's tiles)
   // f16, fused with the x-projection (lstm16f_kernel; xsrc == nullptr: z comes from the projection GEMM as above)

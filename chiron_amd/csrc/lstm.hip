@@ -829,6 +829,152 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32, wide form (round 3): one workgroup = SIXTEEN batch rows x one direction on v_mfma_f32_16x16x4_f32
+// (M = 16 rows, N = 16 columns = 4 units x 4 gates, K = 4; 8 passes = 32 cycles for 2048 FLOP: the full 64 FLOP/clk/SIMD,
+// where the 4x4x1 form of lstm_kernel pays 10 cycles for 512 FLOP).  B = 1100 gives 69 x 2 = 138 workgroups of 8 waves,
+// one per CU: on its own such a launch uses 54 % of the CUs and takes about as long as the 550 four-row workgroups that
+// fill the chip twice over -- but the engine keeps three batches in flight, and what counts there is CU-time: a layer's
+// recurrence costs 138 CUs x 1.1 ms instead of 256 CUs x 1.1 ms, and the other batches' GEMMs run on the CUs it leaves
+// alone (the 4-row form's two workgroups per CU hold 496 of a SIMD's 512 registers: nothing co-resides with them, while
+// their matrix pipes are 41 % busy).  DESIGN 3.2.
+//   wave w owns the column tiles 3w .. 3w+2 (wave 7: 21 .. 24) of the 25 (H = 100 = 25 x 4 units); their W_hh slices
+//   (25 k-steps x 1 register per tile) stay in VGPRs for the whole sequence;
+//   A = h_{t-1} [16 rows][K = 100]: lane (row = lane & 15, kq = lane >> 4) reads h[row][4 ks + kq] for k-step ks; the LDS
+//     tile is [ks][lane]: reads are lane-linear, and the 64 cells of a column tile write 64 consecutive floats;
+//   D: lane (col = lane & 15 = 4 u + gate, q = lane >> 4) holds rows 4q .. 4q+3 of its column; z arrives in the projection's
+//     layout [4-row group][dir][col = gate*H + unit][4 rows] -- the 16 bytes this lane needs -- and is added in place, then
+//     the 4 x 4 transpose inside each lane quad goes through wave-private LDS (as in lstm16w_kernel) so that lane (q, u, r)
+//     holds i, j, f, o of cell (row 4q + r, unit 4 tile + u).
+// Every row of a batch takes this kernel whatever the batch size (partial last groups included), so a window's result
+// does not depend on the batch it travels in; the accumulation order differs from lstm_kernel's (4 k per MFMA), so the two
+// forms agree to rounding (CHIRON_LSTM_WIDE=1 / =0 selects the form: A/B switch and test partner).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int W32_KS = 25;      // k-steps of 4: K = 100
+constexpr int HW32 = W32_KS * 64;   // floats per h buffer: [ks][kq*16 + row]
+
+__global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w_kernel(const LstmParams p) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2 * HW32];
+  __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * W16_XF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x % p.ndir;
+  const int g16 = blockIdx.x / p.ndir;                 // 16-row group = the 4-row groups 4 g16 .. 4 g16 + 3
+  const int nt = wave == W16_NW - 1 ? 4 : 3;           // column tiles of this wave
+  const int tile0 = 3 * wave;
+
+  float w[W16_NT][W32_KS];
+  {
+    const float* wf = p.wwide32 + ((long)dir * W16_NW + wave) * W16_NT * W32_KS * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+#pragma unroll
+      for (int ks = 0; ks < W32_KS; ++ks) w[n][ks] = wf[(n * W32_KS + ks) * 64];
+  }
+  for (int i = tid; i < 2 * HW32; i += 64 * W16_NW) hbuf[i] = 0.f;
+
+  const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;   // before the transpose: column 4u + gp, rows 4q .. 4q+3
+  const int row = 4 * q + gp;                                      // after it: this lane's cell is (row, unit 4 tile + u)
+  const int brow = g16 * 16 + row;
+  const int lenr = min(p.seq_len[brow], p.T);
+  int maxlen = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) maxlen = max(maxlen, min(p.seq_len[g16 * 16 + r], p.T));
+  __syncthreads();
+
+  const unsigned outw = p.ndir * p.H;
+  const unsigned zcols = 4 * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;        // floats between consecutive steps
+  // byte offset of this lane's 16 bytes (rows 4q..4q+3 of column gate*H + unit) for tile slot 0; + 64 bytes per tile
+  const unsigned zlane_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 4 * tile0 + u) * 4) * 4;
+  const unsigned ostep = p.BP * outw;
+  const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;  // + 4 per tile
+  const int hw = tile0 * 64 + u * 16 + row;                         // + 64 per tile: [ks = tile][kq = u][row]
+
+  // transpose scratch: lane l = (q, u, gp) stores its 4 rows at float 4 l + 4 q; lane (q, u, r) then reads gate g at
+  // float 4 (16 q + 4 u + g) + 4 q + r: bank 16 u + 4 g + 4 q + r, distinct over the wave for every g
+  float* const xw = xf + wave * W16_NT * W16_XF + 4 * lane + 4 * q;
+  const float* const xr = xf + wave * W16_NT * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+
+  float c[W16_NT] = {0.f, 0.f, 0.f, 0.f}, hprev[W16_NT] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (int s = 0; s < maxlen; ++s) {
+    const float* zs = p.z + (size_t)s * zstep;   // wave-uniform
+    f32x4 z4[W16_NT];
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z4[0]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(z4[1]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=v"(z4[2]) : "v"(zlane_b), "s"(zs) : "memory");
+    if (nt == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192" : "=v"(z4[3]) : "v"(zlane_b), "s"(zs) : "memory");
+    else z4[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* hb = hbuf + cur * HW32 + lane;
+    float hv[W32_KS];
+#pragma unroll
+    for (int ks = 0; ks < W32_KS; ++ks) hv[ks] = hb[ks * 64];
+    f32x4 acc[W16_NT];
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef CHIRON_W32_VARIANT
+#define CHIRON_W32_VARIANT 0   // timing experiments only (tools/variants.sh): 1 no gate math, 2 no MFMAs, 3 no transpose
+#endif
+#if CHIRON_W32_VARIANT == 2
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) acc[n][0] = hv[n] + w[n][0] + hv[n + 8] + hv[24];
+#else
+#pragma unroll
+    for (int ks = 0; ks < W32_KS; ++ks) {
+#pragma unroll
+      for (int n = 0; n < W16_NT; ++n)
+        if (n < nt) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[ks], w[n][ks], acc[n], 0, 0, 0);
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z4[0]), "+v"(z4[1]), "+v"(z4[2]), "+v"(z4[3]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    const bool act = s < lenr;
+    const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+#if CHIRON_W32_VARIANT != 3
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+      if (n < nt) *reinterpret_cast<f32x4*>(xw + n * W16_XF) = acc[n] + z4[n];
+    __builtin_amdgcn_wave_barrier();   // wave-private scratch: LDS operations of a wave execute in order
+#endif
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      if (n < nt) {
+        const float* xs = xr + n * W16_XF;
+#if CHIRON_W32_VARIANT == 3
+        const f32x4 gates = acc[n] + z4[n];
+#else
+        const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};   // i, j, f, o of (row, unit 4 (tile0 + n) + u)
+#endif
+        float hnew;
+#if CHIRON_W32_VARIANT == 1
+        const float cn = gates[0] + gates[1] * 0.001f;
+        hnew = gates[2] * 0.001f + gates[3] * 0.002f;
+#else
+        const float cn = lstm_cell(gates, c[n], &hnew);
+#endif
+        c[n] = act ? cn : c[n];
+        hprev[n] = act ? hnew : hprev[n];
+        hbuf[(cur ^ 1) * HW32 + hw + 64 * n] = hprev[n];
+        const unsigned ob = (to * ostep + olane + 4 * n) * 4u;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + ob) = act ? hnew : 0.f;
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+
+  // ---- frames past the longest row of the workgroup read back as zeros (dynamic_rnn semantics)
+  for (int s = maxlen; s < p.T; ++s)
+    for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
+      const int r = i / p.H;
+      const int uu = i - r * p.H;
+      p.out[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = 0.f;
+    }
+}
+
 static int lstm_cu_count() { return current_device_cus(); }
 
 void launch_lstm(const LstmParams& p0, hipStream_t stream) {
@@ -859,6 +1005,10 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
     if (wide > 0) hipLaunchKernelGGL(lstm16w_kernel, dim3(wide * p.ndir), dim3(64 * W16_NW), 0, stream, p);
     p.group0 = 4 * wide;
     if (groups > p.group0) hipLaunchKernelGGL(lstm16_kernel, dim3((groups - p.group0) * p.ndir), dim3(64 * LSTM_NW), 0, stream, p);
+    return;
+  }
+  if (p.wwide32 && !p.narrow32 && !p.paired) {   // the default: sixteen-row workgroups for every row of the padded batch
+    hipLaunchKernelGGL(lstm32w_kernel, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
     return;
   }
   // Paired workgroups (one per CU) for as many groups as fit ONE resident round, 7-wave workgroups for the rest: a

@@ -38,7 +38,7 @@ def saturated_gate_weights(spec, name, seed=9):
     return w
 
 
-def trained_like_weights(spec, x_calib, seed=5, lstm_gain=3.0, gate_spread=3.0, chan_sigma=1.0):
+def trained_like_weights(spec, x_calib, seed=5, lstm_gain=3.0, gate_spread=3.0, chan_sigma=1.0, filter_mean=0.6):
     from oracle import nn_oracle
     w = ca.synthetic_weights(spec, seed=seed, lstm_gain=lstm_gain)
     rng = np.random.RandomState(seed + 1000)
@@ -49,7 +49,7 @@ def trained_like_weights(spec, x_calib, seed=5, lstm_gain=3.0, gate_spread=3.0, 
             if cin > 1:
                 a = a * np.exp(rng.normal(0.0, chan_sigma, (1, 1, cin, 1)))
                 if "/branch1/" not in k:           # the shortcut of blocks 2, 3 has no BN behind it: leave its mean alone
-                    a = a + rng.normal(0.0, 0.6 / np.sqrt(kk * cin), (1, 1, 1, cout))
+                    a = a + rng.normal(0.0, filter_mean / np.sqrt(kk * cin), (1, 1, 1, cout))
                 else:
                     a = a * np.exp(-0.5 * chan_sigma * chan_sigma) * 0.5
             w[k] = a.astype(np.float32)

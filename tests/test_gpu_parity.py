@@ -355,7 +355,7 @@ def test_pipeline_end_to_end_on_example_signal(dna, tmp_path):
 
 def test_paired_recurrence_workgroups_give_identical_bits(dna, monkeypatch):
     """lstm.hip lstm_kernel<2> (CHIRON_LSTM_PAIR=1: two 4-row groups per workgroup, 14 waves, for the rows that fit one
-    resident round) and lstm_kernel<1> do the same arithmetic for a row -- heavy waves 100 MFMAs in k order, the light
+    resident round) and lstm_kernel<1> (both with CHIRON_LSTM_WIDE=0) do the same arithmetic for a row -- heavy waves 100 MFMAs in k order, the light
     wave its K-split sum in a fixed order -- so logits are bit-identical whichever form a row meets, ragged rows and
     zero-length rows included, and equal to the oracle within the fp32 bound."""
     from oracle import nn_oracle
@@ -365,19 +365,58 @@ def test_paired_recurrence_workgroups_give_identical_bits(dna, monkeypatch):
     ln = ln.copy()
     ln[[2, 9, 33]] = [0, 1, 250]
     out = []
-    for paired in (False, True):
+    for paired in (False, True):                               # the 7-wave form, the 14-wave form (both 4-row kernels)
+        monkeypatch.setenv("CHIRON_LSTM_WIDE", "0")
+        monkeypatch.delenv("CHIRON_LSTM_PAIR", raising=False)
         if paired:
             monkeypatch.setenv("CHIRON_LSTM_PAIR", "1")
-        else:
-            monkeypatch.delenv("CHIRON_LSTM_PAIR", raising=False)
         with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
             sl = ca.seq_len_for_engine(ln, eng.ratio)
             out.append(eng.infer(x, sl, want_logits=True).logits.copy())
+    monkeypatch.delenv("CHIRON_LSTM_WIDE", raising=False)
     monkeypatch.delenv("CHIRON_LSTM_PAIR", raising=False)
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
     rows = [0, 2, 9, 33, 69]
     ref, _ = nn_oracle.inference(x[rows], sl[rows], spec.to_dict(), w, dtype=np.float64)
     assert np.abs(out[0][rows] - ref).max() < TOL
+
+
+def test_wide_recurrence_agrees_with_the_narrow_form_and_is_repack_stable(dna, rna, monkeypatch):
+    """lstm32w_kernel (CHIRON_LSTM_WIDE=1: sixteen rows per workgroup on v_mfma_f32_16x16x4_f32) against lstm_kernel<1>
+    (CHIRON_LSTM_WIDE=0: four rows on v_mfma_f32_4x4x1): the same function with a different order of the
+    fp32 accumulation (4 k per MFMA instead of 1) -- logits agree to rounding (1e-5), both are within the 1e-4 bound of
+    the float64 oracle, and they are NOT bit-identical (the switch really selects the kernel).  Every row of a batch
+    takes the same kernel whatever the batch size, so a window's logits do not depend on the batch it travels in: a row
+    alone, in a 5-row batch, at another position of a 70-row batch and in an engine of another max_batch gives the same
+    bits (per-read sharding and re-packing rely on it).  Ragged, 1-frame and empty rows; DNA stack and RNA MultiRNN."""
+    from oracle import nn_oracle
+    for (spec, w), L, jump in ((dna, 400, 390), (rna, 500, 490)):
+        B = 70
+        x, ln = _windows(jump * (B - 1) + 123, L, jump, seed=43)
+        ln = ln.copy()
+        ln[[2, 9, 33, 47]] = [0, 5, L // 2, L - 7]        # 5 samples: 5 frames for DNA, 1 frame for RNA (ratio 5)
+        out = {}
+        for form in ("wide", "narrow"):
+            monkeypatch.setenv("CHIRON_LSTM_WIDE", "1" if form == "wide" else "0")
+            with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
+                sl = ca.seq_len_for_engine(ln, eng.ratio)
+                out[form] = eng.infer(x, sl, want_logits=True).logits.copy()
+                if form == "wide":
+                    assert np.array_equal(eng.infer(x, sl, want_logits=True).logits, out[form])     # deterministic
+                    perm = np.random.RandomState(5).permutation(B)
+                    shuffled = eng.infer(x[perm], sl[perm], want_logits=True).logits
+                    assert np.array_equal(shuffled, out[form][perm])                              # any row slot, same bits
+                    few = [47, 2, 33, 0, 9]
+                    assert np.array_equal(eng.infer(x[few], sl[few], want_logits=True).logits, out[form][few])
+                    assert np.array_equal(eng.infer(x[33:34], sl[33:34], want_logits=True).logits, out[form][33:34])
+        monkeypatch.setenv("CHIRON_LSTM_WIDE", "1")
+        with ca.Engine(spec, w, max_batch=23, segment_len=L) as small:
+            assert np.array_equal(small.infer(x[40:63], sl[40:63], want_logits=True).logits, out["wide"][40:63])
+        monkeypatch.delenv("CHIRON_LSTM_WIDE", raising=False)
+        diff = np.abs(out["wide"] - out["narrow"]).max()
+        assert 0 < diff < 1e-5, diff
+        ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+        assert np.abs(out["wide"] - ref).max() < TOL and np.abs(out["narrow"] - ref).max() < TOL
 
 
 def test_winograd_conv2b_against_direct_form_and_oracle(dna, rna, monkeypatch):
@@ -422,12 +461,14 @@ def test_winograd_conv2b_against_direct_form_and_oracle(dna, rna, monkeypatch):
 def _engine_variants(monkeypatch):
     """(name, dtype, env) of every recurrence / convolution form the regimes are driven through.  The f16 forms are held to
     the fp32 ENGINE (the f16 bound of test_f16_path_tolerance_vs_f32), the fp32 forms to the float64 oracle."""
-    return (("fp32", "fp32", {}), ("fp32-paired", "fp32", {"CHIRON_LSTM_PAIR": "1"}), ("fp32-split", "fp32-split", {}),
+    return (("fp32", "fp32", {"CHIRON_LSTM_WIDE": "0"}), ("fp32-wide", "fp32", {"CHIRON_LSTM_WIDE": "1"}),
+            ("fp32-paired", "fp32", {"CHIRON_LSTM_WIDE": "0", "CHIRON_LSTM_PAIR": "1"}),
+            ("fp32-split", "fp32-split", {}),
             ("fp16-fused", "fp16", {"CHIRON_LSTM16_FUSED_MIN": "1"}), ("fp16-unfused", "fp16", {"CHIRON_LSTM16_UNFUSED": "1"}),
             ("fp16-narrow", "fp16", {"CHIRON_LSTM16_NARROW": "1"}))
 
 
-_REGIME_ENV = ("CHIRON_LSTM_PAIR", "CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED", "CHIRON_LSTM16_NARROW", "CHIRON_NO_WINOGRAD",
+_REGIME_ENV = ("CHIRON_LSTM_PAIR", "CHIRON_LSTM_WIDE", "CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED", "CHIRON_LSTM16_NARROW", "CHIRON_NO_WINOGRAD",
                "CHIRON_WINOGRAD_F2")
 
 
@@ -506,9 +547,9 @@ def test_trained_like_weights_through_every_conv_form(dna, rna, monkeypatch, cas
     Stage 1 -- getcnnfeature: the engine's CNN features (Winograd F(4,3) / F(2,3) / direct conv2b, table form of block 1)
     against the float64 oracle, relative to the feature scale; the re-associated forms may not lose more than 4x what the
     direct form loses.  Stage 2 -- logits of every recurrence form.  The recurrent stack amplifies what it is fed (the
-    float32 numpy restatement of the SAME formulas deviates from float64 by more than 1e-4 for some of these weights), so
-    the bound on logits is 1e-4 or 4x the float32 restatement's own deviation, whichever is larger; the measured figures
-    are written to gpurun_out/parity_trained_like_*.json."""
+    float32 numpy restatement of the SAME formulas deviates from float64 by 1.4e-4 .. 7.5e-4 for these weights), so
+    the bound on logits is 1e-4 or 4x the float32 restatement's own deviation, whichever is larger (fp32-split: 8x); the
+    measured figures are written to gpurun_out/parity_trained_like_*.json and quoted in DESIGN.md."""
     import regimes
     from oracle import nn_oracle
     spec, L, jump = {"dna-f4": (dna[0], 400, 390), "rna-f4": (rna[0], 500, 490), "dna-f2": (dna[0], 398, 390)}[case]
@@ -525,7 +566,7 @@ def test_trained_like_weights_through_every_conv_form(dna, rna, monkeypatch, cas
     report["feature_max"] = scale
     report["feature_rms"] = float(np.sqrt((fea64 ** 2).mean()))
     report["features/numpy-fp32"] = float(np.abs(fea32 - fea64).max())
-    errs = {}
+    errs, failures = {}, []
     for form, env in (("default", {}), ("f2", {"CHIRON_WINOGRAD_F2": "1"}), ("direct", {"CHIRON_NO_WINOGRAD": "1"})):
         got, sl, fea = _run_variant(monkeypatch, spec, w, x, ln, L, "fp32", env, features=True)
         errs[form] = float(np.abs(fea - fea64).max())
@@ -534,13 +575,21 @@ def test_trained_like_weights_through_every_conv_form(dna, rna, monkeypatch, cas
     # features: absolute bound relative to their scale (fp32 has 2^-24 per operation; K = 768 products per output, BN shift
     # cancelling conv outputs several times larger than the result)
     for form, e_ in errs.items():
-        assert e_ < 2e-5 * max(scale, 1.0), (form, e_, scale)
-        assert e_ < 4 * max(errs["direct"], report["features/numpy-fp32"]), (form, errs)
+        if not e_ < 2e-5 * max(scale, 1.0):
+            failures.append(("features", form, e_, scale))
+        if not e_ < 4 * max(errs["direct"], report["features/numpy-fp32"]):
+            failures.append(("features vs direct form", form, errs))
     ref, _ = nn_oracle.inference(x, sl, sd, w, dtype=np.float64)
     r32, _ = nn_oracle.inference(x, sl, sd, w, dtype=np.float32)
     own = float(np.abs(r32 - ref).max())
     report["logits/numpy-fp32"] = own
-    bound = max(TOL, 4 * own)
+    # What half precision costs THIS network, measured without any kernel: the float64 oracle on weights rounded to halves.
+    # These weights amplify a 5e-4 relative perturbation into tenths of a logit (BN sites cancel conv outputs several
+    # times larger than what they pass on), so the f16 engine cannot be held to configs[4]'s 0.08 here: its deviation
+    # from the fp32 engine is reported and held to a multiple of that figure (no NaN / inf, no gross error).
+    p16, _ = nn_oracle.inference(x, sl, sd, {k: v.astype(np.float16).astype(np.float32) for k, v in w.items()}, dtype=np.float64)
+    f16_proxy = float(np.abs(p16 - ref).max())
+    report["logits/float64-oracle-on-f16-rounded-weights"] = f16_proxy
     got32 = None
     for vname, dtype, env in _engine_variants(monkeypatch):
         got, sl, _ = _run_variant(monkeypatch, spec, w, x, ln, L, dtype, env)
@@ -549,14 +598,18 @@ def test_trained_like_weights_through_every_conv_form(dna, rna, monkeypatch, cas
             mask = (np.arange(got.shape[1])[None, :] < sl[:, None])[..., None]
             err = float((np.abs(got - got32) * mask).max())
             report["logits/%s-vs-fp32-engine" % vname] = err
-            assert err < 0.25, (vname, err)
+            if not err < max(0.08, 8 * f16_proxy):
+                failures.append((vname, err, f16_proxy))
         else:
             err = float(np.abs(got - ref).max())
             report["logits/" + vname] = err
-            assert err < bound, (vname, err, own)
+            # fp32-split carries 22 mantissa bits between kernels (hi + lo halves), fp32 carries 24
+            if not err < max(TOL, (8 if dtype == "fp32-split" else 4) * own):
+                failures.append((vname, err, own))
             if vname == "fp32":
                 got32 = got
     _dump_report("trained_like_%s" % case, report)
+    assert not failures, (failures, report)
 
 
 def _beam_rows(res, B):
