@@ -79,11 +79,21 @@ SYMBOLS = [
     ("chiron_parse_signal_text", C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("chiron_assemble", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_double,
                                   C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    ("chiron_finish_read", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_char_p,
+                                     C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     ("chiron_overlap_displacement", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
                                               C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("chiron_consensus_device", C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     ("chiron_crc32c", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    ("chiron_fast5_open", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    ("chiron_fast5_close", None, [C.c_void_p]),
+    ("chiron_fast5_read_count", C.c_int32, [C.c_void_p]),
+    ("chiron_fast5_read_info", C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int64)]),
+    ("chiron_fast5_signal", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
+    ("chiron_fast5_fastq", C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]),
+    ("chiron_write_signal_text", C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p]),
     ("chiron_last_error", C.c_char_p, []),
     ("chiron_abi_version", C.c_int32, []),
 ]

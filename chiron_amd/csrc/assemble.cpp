@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/chiron_amd.h"
@@ -178,6 +179,22 @@ int64_t displacement(int32_t kernal, const uint8_t* cur, int64_t n, const uint8_
 
 bool known_kernal(int32_t k) { return k == CHIRON_KERNAL_GLUE || k == CHIRON_KERNAL_STICK || k == CHIRON_KERNAL_SIMPLE; }
 
+// pass 1 of the vote: where every segment starts (running position; may be negative with the simple kernel) -> length
+int64_t segment_starts(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, int32_t kernal, double error_rate, double jump_step_ratio,
+                       std::vector<int64_t>& start) {
+  start.assign((size_t)std::max<int64_t>(n_seg, 0), 0);
+  int64_t pos = 0, length = 0;
+  for (int64_t s = 1; s < n_seg; ++s) {
+    const int64_t n = seg_off[s + 1] - seg_off[s], pn = seg_off[s] - seg_off[s - 1];
+    pos += displacement(kernal, bases + seg_off[s], n, bases + seg_off[s - 1], pn, error_rate, jump_step_ratio, nullptr);
+    start[(size_t)s] = pos;
+    length = std::max(length, pos + n);
+  }
+  return length;
+}
+void cast_votes(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs, const std::vector<int64_t>& start, int64_t length,
+                double* counts, double* qs_sum, int64_t cap);
+
 }  // namespace
 
 extern "C" chiron_status chiron_overlap_displacement(const uint8_t* cur, int64_t n, const uint8_t* prev, int64_t prev_n, int32_t kernal,
@@ -194,15 +211,8 @@ extern "C" chiron_status chiron_assemble(const uint8_t* bases, const int64_t* se
                                          int64_t* out_len) {
   if (!seg_off || !out_len || n_seg < 0) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_assemble: bad arguments");
   if (!known_kernal(kernal)) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_assemble: kernal %d (1 = glue, 2 = stick, 3 = simple)", kernal);
-  // pass 1: where every segment starts (running position; may be negative with the simple kernel) and the length
-  std::vector<int64_t> start((size_t)n_seg, 0);
-  int64_t pos = 0, length = 0;
-  for (int64_t s = 1; s < n_seg; ++s) {
-    const int64_t n = seg_off[s + 1] - seg_off[s], pn = seg_off[s] - seg_off[s - 1];
-    pos += displacement(kernal, bases + seg_off[s], n, bases + seg_off[s - 1], pn, error_rate, jump_step_ratio, nullptr);
-    start[(size_t)s] = pos;
-    length = std::max(length, pos + n);
-  }
+  std::vector<int64_t> start;
+  const int64_t length = segment_starts(bases, seg_off, n_seg, kernal, error_rate, jump_step_ratio, start);
   *out_len = length;
   if (length > cap) return chiron::set_error(CHIRON_ERR_OVERFLOW, "chiron_assemble: consensus needs %lld columns, capacity %lld", (long long)length, (long long)cap);
   if (length == 0) return CHIRON_OK;
@@ -211,8 +221,15 @@ extern "C" chiron_status chiron_assemble(const uint8_t* bases, const int64_t* se
     memset(counts + r * cap, 0, sizeof(double) * length);
     if (qs_sum) memset(qs_sum + r * cap, 0, sizeof(double) * length);
   }
-  // pass 2: votes.  A segment starting left of column 0 loses its head (add_count); columns beyond `length` are
-  // dropped exactly like concensus[:, :length] (only segment 0 can reach past it)
+  cast_votes(bases, seg_off, n_seg, seg_qs, start, length, counts, qs_sum, cap);
+  return CHIRON_OK;
+}
+
+namespace {
+// pass 2 of the vote.  A segment starting left of column 0 loses its head (add_count); columns beyond `length` are
+// dropped exactly like concensus[:, :length] (only segment 0 can reach past it)
+void cast_votes(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs, const std::vector<int64_t>& start, int64_t length,
+                double* counts, double* qs_sum, int64_t cap) {
   for (int64_t s = 0; s < n_seg; ++s) {
     const int64_t n = seg_off[s + 1] - seg_off[s];
     const uint8_t* seg = bases + seg_off[s];
@@ -225,6 +242,122 @@ extern "C" chiron_status chiron_assemble(const uint8_t* bases, const int64_t* se
       counts[b * cap + colx] += 1.0;
       if (qs_sum && seg_qs) qs_sum[b * cap + colx] += q;
     }
+  }
+}
+}  // namespace
+
+// ---- one read from decoded windows to its files, without the interpreter (chiron_eval.py:446-462 + write_output
+// :176-228): index2base of every window, the vote above, np.argmax (first maximum, :457), qs (:152-174; the same
+// decisions as chiron_amd/eval.py qs(): the quality belongs to the LAST of equal top counts, a column nobody voted for
+// scores 0), and the result / segments files in the reference's formats.  ctypes releases the GIL for the whole call, so
+// the finishing threads of `chiron call` run in parallel; behind the fp16 engine they were what bounded the pipeline.
+namespace {
+bool write_file(const char* path, const std::string& text) {
+  FILE* f = fopen(path, "wb");
+  if (!f) return false;
+  const size_t w = text.empty() ? 0 : fwrite(text.data(), 1, text.size(), f);
+  return (fclose(f) == 0) && w == text.size();
+}
+}  // namespace
+
+extern "C" chiron_status chiron_finish_read(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs, int32_t kernal,
+                                            double error_rate, double jump_step_ratio, const char* name, const char* result_path,
+                                            const char* segments_path, int32_t fastq, int32_t rna, char* consensus_out, int64_t consensus_cap,
+                                            int64_t* consensus_len) {
+  if (!seg_off || n_seg < 0 || !name || !result_path || !consensus_len || (n_seg > 0 && seg_off[n_seg] > 0 && !bases))
+    return chiron::set_error(CHIRON_ERR_INVALID, "chiron_finish_read: bad arguments");
+  if (!known_kernal(kernal)) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_finish_read: kernal %d (1 = glue, 2 = stick, 3 = simple)", kernal);
+  static const char ACGT[4] = {'A', 'C', 'G', 'T'};
+  const bool want_q = fastq != 0 && seg_qs != nullptr;
+  std::vector<int64_t> start;
+  const int64_t length = segment_starts(bases, seg_off, n_seg, kernal, error_rate, jump_step_ratio, start);
+  // the vote of cast_votes() with the four bases of a column next to each other ([column][base]: one cache line serves
+  // four columns; the [base][column] matrices of chiron_assemble are what numpy wants, not what this loop wants)
+  std::vector<float> counts;      // vote counts are small integers: exact in float
+  std::vector<double> qsum;
+  if (length > 0) {
+    counts.assign((size_t)4 * length, 0.f);
+    if (want_q) qsum.assign((size_t)4 * length, 0.0);
+    for (int64_t s = 0; s < n_seg; ++s) {
+      const int64_t n = seg_off[s + 1] - seg_off[s];
+      const uint8_t* seg = bases + seg_off[s];
+      const double q = want_q ? seg_qs[s] : 0.0;
+      const int64_t st = start[(size_t)s];
+      for (int64_t j = st < 0 ? -st : 0; j < n; ++j) {
+        const int64_t colx = st + j;
+        if (colx >= length) break;
+        const size_t at = (size_t)colx * 4 + (seg[j] & 3);
+        counts[at] += 1.f;
+        if (want_q) qsum[at] += q;      // added in segment order, like add_count_qs
+      }
+    }
+  }
+  std::string seq((size_t)length, 'A'), qual;
+  if (want_q) qual.assign((size_t)length, '!');
+  const double ln10 = std::log(10.0);
+  constexpr int QTAB = 64;
+  struct QTable {
+    double v[QTAB][QTAB];
+    QTable() {
+      for (int a = 0; a < QTAB; ++a)
+        for (int b = 0; b < QTAB; ++b) v[a][b] = 10.0 * std::log10(((double)a + 1.0) / ((double)b + 1.0));
+    }
+  };
+  static const QTable qtab;
+  for (int64_t c = 0; c < length; ++c) {
+    const float* cc = &counts[(size_t)c * 4];
+    double n1 = cc[0];
+    int arg = 0, top = 0;
+    for (int b = 1; b < 4; ++b)
+      if (cc[b] > n1) n1 = cc[b], arg = b;   // np.argmax: first maximum
+    seq[(size_t)c] = ACGT[arg];
+    if (!want_q) continue;
+    for (int b = 0; b < 4; ++b)
+      if (cc[b] == n1) top = b;              // last of the maxima (stable argsort)
+    double n2 = -1.0;
+    for (int b = 0; b < 4; ++b)
+      if (b != top && cc[b] > n2) n2 = cc[b];
+    long long q = 0;
+    if (n1 > 0) {
+      // vote counts are small integers: 10 log10((n1 + 1) / (n2 + 1)) comes from a table of the same expression
+      const double ratio_db = (n1 < QTAB && n2 >= 0 && n2 < QTAB) ? qtab.v[(int)n1][(int)n2] : 10.0 * std::log10((n1 + 1.0) / (n2 + 1.0));
+      q = (long long)(ratio_db + qsum[(size_t)c * 4 + top] / n1 / ln10);
+    }
+    const long long code = q + 33;
+    if (code < 0 || code > 127)
+      return chiron::set_error(CHIRON_ERR_INVALID, "chiron_finish_read: quality code %lld of column %lld is not one ASCII byte", code, (long long)c);
+    qual[(size_t)c] = (char)code;
+  }
+  // result/<name>.fastq = @name / sequence / + / quality, each line terminated; .fasta = >name / sequence, no final newline
+  std::string text;
+  text.reserve((size_t)2 * length + 64);
+  text.append(want_q ? "@" : ">").append(name).append("\n");
+  const size_t seq_at = text.size();
+  text.append(seq);
+  if (rna)   // chiron_eval.py:204-205: the written consensus only (the caller's string keeps T, as finish_read returns it)
+    for (size_t i = seq_at; i < text.size(); ++i)
+      if (text[i] == 'T') text[i] = 'U';
+  if (want_q) text.append("\n+\n").append(qual).append("\n");
+  if (!write_file(result_path, text)) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_finish_read: cannot write %s", result_path);
+  if (segments_path) {
+    // segments/<name>.<ext>: one FASTA-style record per window, named <name><window index> (never T -> U: the reference
+    // converts the consensus only, chiron_eval.py:204-205)
+    std::string segs;
+    segs.reserve((size_t)(seg_off[n_seg] - seg_off[0]) + (size_t)n_seg * (strlen(name) + 12));
+    char num[24];
+    for (int64_t s = 0; s < n_seg; ++s) {
+      segs.append(">").append(name);
+      snprintf(num, sizeof(num), "%lld", (long long)s);
+      segs.append(num).append("\n");
+      for (int64_t j = seg_off[s]; j < seg_off[s + 1]; ++j) segs.push_back(ACGT[bases[j] & 3]);
+      segs.push_back('\n');
+    }
+    if (!write_file(segments_path, segs)) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_finish_read: cannot write %s", segments_path);
+  }
+  *consensus_len = length;
+  if (consensus_out) {
+    if (length > consensus_cap) return chiron::set_error(CHIRON_ERR_OVERFLOW, "chiron_finish_read: consensus of %lld bases, capacity %lld", (long long)length, (long long)consensus_cap);
+    memcpy(consensus_out, seq.data(), (size_t)length);
   }
   return CHIRON_OK;
 }

@@ -58,8 +58,25 @@ def evaluation(args):
     if device is not None:
         FLAGS.device = device
     if path.isdir(FLAGS.input):
-        from .extract import list_fast5
-        if list_fast5(FLAGS.input, True):
+        from .extract import list_fast5, prepare_folders
+        fast5_list = list_fast5(FLAGS.input, True, getattr(FLAGS, "test_number", None))
+        if fast5_list and not getattr(FLAGS, "via_signal_files", False):
+            # Direct path: ONE partition decides which rank decodes and basecalls a fast5 file; the reader
+            # threads write raw/<name>.signal for the output tree and window the decoded samples straight away -- no
+            # extract-everything barrier, no text parsed back.
+            import os
+            prepare_folders(FLAGS, rank, world)
+            FLAGS.input = FLAGS.output + "/raw/"          # what the .meta files record (entry.py:38)
+            sizes = {f: os.path.getsize(f) for f in fast5_list}
+            FLAGS.fast5_files = shard.partition_reads(fast5_list, world, rank, sizes)
+            if dist is None:
+                return chiron_eval.run(args)
+            out = shard.run_sharded(FLAGS, lambda fl, mine: chiron_eval.evaluation(fl, fast5_files=fl.fast5_files), dist,
+                                    partition=False)
+            dist.destroy_process_group()
+            return out
+        if fast5_list:
+            # the reference's own two passes (entry.py:33-38): extract every file to raw/*.signal, then basecall raw/
             extract(FLAGS, rank, world)
             if dist is not None:
                 dist.barrier()
@@ -98,6 +115,9 @@ def build_parser():
     p.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp32-split"],
                    help="Engine arithmetic: fp32 (parity path), fp16 (f16 MFMA conv + LSTM, fp32 CTC), fp32-split "
                         "(fp32 values as hi/lo half pairs on the f16 matrix cores).")
+    p.add_argument("--via-signal-files", dest="via_signal_files", action="store_true",
+                   help="fast5 input: the reference's two passes (extract everything to raw/*.signal, then parse the text back) "
+                        "instead of windowing the decoded samples directly; same output files.")
     p.add_argument("--synthetic-weights", dest="synthetic_weights", action="store_true",
                    help="Use seeded synthetic weights when the model folder has no checkpoint data.")
     p.set_defaults(func=evaluation)

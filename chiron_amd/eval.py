@@ -308,16 +308,22 @@ class ReadCollector(object):
         return done
 
     def _finish(self, name, want_qs):
+        """-> (name, flat, seg_len, qs_list, meta): the read's decoded windows as ONE uint8 array of base indices and the
+        length of every window that decoded to something (rows with an empty decode vanish, as in sparse2dense,
+        chiron_eval.py:36-66); qs_list holds the path_prob of exactly those rows."""
         rec = self.val.pop(name)
-        reads = []
-        qs_list = np.empty((0, 1), dtype=float)
+        vals, lens, qss = [], [], []
         for i in sorted(rec["pieces"]):
-            predict_val, logits_prob = rec["pieces"][i]
-            predict_read, unique = sparse2dense(predict_val)
+            (decoded, _), logits_prob = rec["pieces"][i]
+            ids, starts, ends = _rows_of(decoded[0])
+            vals.append(decoded[0].values)
+            lens.append(ends - starts)
             if want_qs:
-                qs_list = np.concatenate((qs_list, logits_prob[unique[0]]))
-            reads += predict_read[0]
-        return name, reads, qs_list, rec["meta"]
+                qss.append(logits_prob[ids])
+        flat = np.concatenate(vals).astype(np.uint8) if vals else np.zeros(0, dtype=np.uint8)
+        seg_len = np.concatenate(lens).astype(np.int64) if lens else np.zeros(0, dtype=np.int64)
+        qs_list = np.concatenate(qss) if qss else np.empty((0, 1), dtype=float)
+        return name, flat, seg_len, qs_list, rec["meta"]
 
 
 def list_inputs(input_path, recursive):
@@ -359,6 +365,53 @@ def finish_read(name, reads, qs_list, FLAGS, t_start, reading_time):
     return c_bpread
 
 
+def split_flat(flat, seg_len):
+    """the ragged list of windows behind the flat form (one array of base indices per window)"""
+    ends = np.cumsum(seg_len)
+    return [flat[e - n:e] for e, n in zip(ends.tolist(), np.asarray(seg_len).tolist())]
+
+
+def finish_read_flat(name, flat, seg_len, qs_list, FLAGS, t_start, reading_time):
+    """finish_read on the flat form of a read's decoded windows (all bases as one uint8 array + the length of every
+    window): one call into chiron_finish_read (bases, vote, argmax, quality string, result/ and segments/ files, all
+    without the interpreter and without the GIL), then the meta file.  Same files as finish_read, byte for byte (tests).
+    Reads long enough for the device vote, and anything the native writer does not cover, take finish_read."""
+    import ctypes as C
+    from . import _lib
+    kernal = get_assembler_kernal(FLAGS.jump, FLAGS.segment_len)
+    n_seg = int(seg_len.shape[0])
+    if getattr(FLAGS, "python_finish", False) or \
+            (kernal != "simple" and n_seg >= getattr(FLAGS, "device_vote_min_segments", DEVICE_VOTE_MIN_SEGMENTS)):
+        return finish_read(name, split_flat(flat, seg_len), qs_list, FLAGS, t_start, reading_time)
+    file_pre = os.path.splitext(name)[0]
+    basecall_time = time.time() - t_start
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    off = np.zeros(n_seg + 1, dtype=np.int64)
+    np.cumsum(seg_len, out=off[1:])
+    fastq = FLAGS.extension == "fastq"
+    qs_arr = np.ascontiguousarray(np.asarray(qs_list, dtype=np.float64).reshape(n_seg, -1)[:, 0]) if (fastq and n_seg) else None
+    if fastq and qs_arr is None:
+        qs_arr = np.zeros(1, dtype=np.float64)
+    cons = np.empty(max(int(flat.shape[0]), 1), dtype=np.uint8)
+    n = C.c_int64()
+    root, ext = FLAGS.output, FLAGS.extension
+    args = lambda: (flat.ctypes.data, off.ctypes.data, n_seg, None if qs_arr is None else qs_arr.ctypes.data, assembly._kernal_id(kernal), 0.2,
+                    FLAGS.jump / FLAGS.segment_len, file_pre.encode(), os.path.join(root, "result", file_pre + "." + ext).encode(),
+                    None if FLAGS.concise else os.path.join(root, "segments", file_pre + "." + ext).encode(), 1 if fastq else 0,
+                    1 if getattr(FLAGS, "mode", "dna") == "rna" else 0, cons.ctypes.data, cons.shape[0], C.byref(n))
+    lib = _lib.load()
+    st = lib.chiron_finish_read(*args())
+    if st != _lib.OK:
+        # a recursive input puts sub-folders into file_pre: create them on demand and retry once
+        for sub in ("result",) + (() if FLAGS.concise else ("segments", "meta")):
+            os.makedirs(os.path.dirname(os.path.join(root, sub, file_pre)), exist_ok=True)
+        _lib.check(lib.chiron_finish_read(*args()))
+    assembly_time = time.time() - t_start
+    if not FLAGS.concise:
+        OutputTree(root, ext, False).meta(file_pre, n.value, (t_start, reading_time, basecall_time, assembly_time), FLAGS)
+    return cons[:n.value].tobytes().decode("ascii")
+
+
 _FLAG_FIELDS = ("input", "output", "model", "start", "batch_size", "segment_len", "jump", "extension", "concise", "mode", "device",
                 "device_vote_min_segments")
 
@@ -367,24 +420,28 @@ def _finish_read_in_process(name, flat, seg_len, qs_list, flags, t_start, readin
     """finish_read for a worker PROCESS (FLAGS.finish_procs > 0): the decoded windows travel as one flat base array +
     lengths, the settings as a plain dict.  The worker never touches the GPU."""
     import argparse
-    ends = np.cumsum(seg_len)
-    reads = [flat[e - n:e] for e, n in zip(ends.tolist(), seg_len.tolist())]
     flags = dict(flags, device_vote_min_segments=1 << 62)     # host vote only: a worker process must not open the GPU
-    return finish_read(name, reads, qs_list, argparse.Namespace(**flags), t_start, reading_time)
+    return finish_read_flat(name, flat, seg_len, qs_list, argparse.Namespace(**flags), t_start, reading_time)
 
 
-def evaluation(FLAGS, engine=None, file_list=None):
+def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
     """chiron_eval.py:378-463 on one GPU.  `file_list` restricts the reads this process handles
-    (per-read sharding across GPUs)."""
+    (per-read sharding across GPUs).  `fast5_files` (full paths) switches to the direct fast5 path of
+    `chiron call`: every file is decoded by the native reader in a reader thread, its raw/<name>.signal
+    and reference files are written as the reference's extraction writes them (extract.extract_records), and the decoded
+    samples are windowed straight away -- the text is never parsed back.  Output files are the same either way."""
     own_engine = engine is None
     if own_engine:
         spec, weights, _ = model_mod.load_model(FLAGS.model, allow_synthetic=getattr(FLAGS, "synthetic_weights", False))
         engine = Engine(spec, weights, max_batch=FLAGS.batch_size, segment_len=FLAGS.segment_len,
                         device_id=getattr(FLAGS, "device", 0), n_slots=int(getattr(FLAGS, "slots", 0) or 3), max_beam=FLAGS.beam,
                         dtype=getattr(FLAGS, "dtype", "fp32"))
-    files, file_dir = list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
-    if file_list is not None:
-        files = [f for f in files if f in set(file_list)]
+    if fast5_files is None:
+        files, file_dir = list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
+        if file_list is not None:
+            files = [f for f in files if f in set(file_list)]
+    else:
+        files, file_dir = [], None
     for sub in ("segments", "result", "meta"):
         os.makedirs(os.path.join(FLAGS.output, sub), exist_ok=True)
     want_qs = FLAGS.extension == "fastq"
@@ -418,13 +475,11 @@ def evaluation(FLAGS, engine=None, file_list=None):
         batch = inflight[slot]
         res = engine.collect(slot)
         inflight[slot] = None
-        for name, reads, qs_list, meta in collector.add_batch(batch, res, want_qs):
+        for name, flat, seg_len, qs_list, meta in collector.add_batch(batch, res, want_qs):
             if n_procs > 0:
-                seg_len = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
-                flat = np.concatenate(reads).astype(np.uint8) if len(reads) else np.zeros(0, dtype=np.uint8)
                 fut = finishers.submit(_finish_read_in_process, name, flat, seg_len, qs_list, flag_dict, meta[0], meta[1])
             else:
-                fut = finishers.submit(finish_read, name, reads, qs_list, FLAGS, meta[0], meta[1])
+                fut = finishers.submit(finish_read_flat, name, flat, seg_len, qs_list, FLAGS, meta[0], meta[1])
             finishing.append((name, fut))
 
     def launch(batch):
@@ -435,27 +490,36 @@ def evaluation(FLAGS, engine=None, file_list=None):
         inflight[slot] = batch
 
     def load(name):
+        """one input file -> [(read name, DataSet, start time, reading time)]"""
         t0 = time.time()
+        if fast5_files is not None:
+            from . import extract as extract_mod
+            out = []
+            for rname, sig in extract_mod.extract_records(name, FLAGS):       # writes raw/<rname>.signal as extraction does
+                ev, ln = signal_io.window_signal(sig, FLAGS.start, FLAGS.jump, FLAGS.segment_len)
+                out.append((rname + ".signal", signal_io.DataSet(ev, ln), t0, time.time() - t0))
+                t0 = time.time()
+            return out
         ds = signal_io.read_data_for_eval(os.path.join(file_dir, name), FLAGS.start, seg_length=FLAGS.segment_len,
                                           step=FLAGS.jump, reverse_fast5=getattr(FLAGS, "reverse_fast5", False))
-        return ds, t0, time.time() - t0
+        return [(name, ds, t0, time.time() - t0)]
 
-    names = [n for n in files if n.endswith(".signal") or n.endswith(".fast5")]
+    names = list(fast5_files) if fast5_files is not None else [n for n in files if n.endswith(".signal") or n.endswith(".fast5")]
     ahead = collections.deque()
     nxt = 0
     try:
-        for name in names:
+        for _ in names:
             while nxt < len(names) and len(ahead) < 2 * n_threads:
                 ahead.append(readers.submit(load, names[nxt]))
                 nxt += 1
-            ds, t0, t_read = ahead.popleft().result()
-            collector.expect(name, ds.reads_n, (t0, t_read))
-            if ds.reads_n == 0:
-                results[name] = finish_read(name, [], np.empty((0, 1)), FLAGS, t0, t_read)
-                collector.val.pop(name, None)
-                continue
-            for batch in packer.add_read(name, ds.event, ds.event_length):
-                launch(batch)
+            for name, ds, t0, t_read in ahead.popleft().result():
+                collector.expect(name, ds.reads_n, (t0, t_read))
+                if ds.reads_n == 0:
+                    results[name] = finish_read(name, [], np.empty((0, 1)), FLAGS, t0, t_read)     # (the Python writers)
+                    collector.val.pop(name, None)
+                    continue
+                for batch in packer.add_read(name, ds.event, ds.event_length):
+                    launch(batch)
         last = packer.flush()
         if last is not None:
             launch(last)
@@ -476,7 +540,7 @@ def run(args):
     FLAGS = args
     print("The result will be written to %s" % (FLAGS.output))
     os.makedirs(FLAGS.output, exist_ok=True)
-    time_dict = unix_time(evaluation, FLAGS)
+    time_dict = unix_time(evaluation, FLAGS, fast5_files=getattr(FLAGS, "fast5_files", None))
     print("Real time:%5.3f Systime:%5.3f Usertime:%5.3f" % (time_dict["real"], time_dict["sys"], time_dict["user"]))
     meta_folder = os.path.join(FLAGS.output, "meta")
     os.makedirs(meta_folder, exist_ok=True)

@@ -34,31 +34,50 @@ def extract_file(path, mode="dna", unit=False):
     return out
 
 
-def _wrapper(args):
-    full, FLAGS = args
-    file_n = os.path.basename(full)
-    stem = os.path.splitext(file_n)[0]
+def extract_records(full, FLAGS):
+    """extract_file_wrapper (extract_sig_ref.py:92-147) for ONE fast5 file: every read's raw signal is written to
+    raw/<name>.signal (and its reference to reference/<stem>_ref.fastq) exactly as the reference's extraction does, and
+    returned as [(name, float32 signal)] so that the caller can window it directly instead of parsing the text back
+    (SURVEY 8(f)1).  The hot path (`chiron call`: unit = False, entry.py:36) reads through the native reader and writes
+    through the native text writer (csrc/fast5.cpp); the pA conversion (unit = True) keeps the Python reader, which also
+    decodes the channel attributes.  Unreadable files are logged and skipped (:97-117): -> []."""
+    from . import fast5
+    stem = os.path.splitext(os.path.basename(full))[0]
+    unit = getattr(FLAGS, "unit", False)
     try:
-        recs = extract_file(full, FLAGS.mode, getattr(FLAGS, "unit", False))
+        if unit:
+            recs = [(s, np.asarray(r), ref, rid) for s, r, ref, rid in extract_file(full, FLAGS.mode, True)]
+        else:
+            recs = [(r["suffix"], r["signal"], r["fastq"], r["read_id"])
+                    for r in fast5.read_fast5_native(full, reverse=FLAGS.mode == "rna")]     # extract_sig_ref.py:165
         if not recs:
             raise ValueError("Fail in extracting raw signal.")
     except Exception as e:  # noqa: BLE001 -- skip-and-log like the reference
         logger.error("Cannot extract file %s. %s" % (full, e))
-        return 0
-    n = 0
+        return []
+    out = []
     for suffix, raw, reference, read_id in recs:
         if len(raw) == 0:
             logger.error("Cannot extract file %s. Got empty raw signal" % full)
             continue
         name = read_id if getattr(FLAGS, "idname", False) else stem + suffix
-        with open(os.path.join(FLAGS.raw_folder, name + ".signal"), "w+") as f:
-            f.write(FLAGS.delimiter.join([str(v) for v in raw.tolist()]))     # extract_sig_ref.py:122-123
+        sig_path = os.path.join(FLAGS.raw_folder, name + ".signal")
+        if unit:
+            with open(sig_path, "w+") as f:
+                f.write(FLAGS.delimiter.join([str(v) for v in raw.tolist()]))     # extract_sig_ref.py:122-123
+        else:
+            fast5.write_signal_text(sig_path, raw, FLAGS.delimiter)
         if len(reference) > 0:
             head = "@%s\n" % stem
             with open(os.path.join(FLAGS.ref_folder, stem + "_ref.fastq"), "w+") as f:
                 f.write(head + "\n".join(reference.split("\n")[1:]))
-        n += 1
-    return n
+        out.append((name, np.asarray(raw, dtype=np.float32)))
+    return out
+
+
+def _wrapper(args):
+    full, FLAGS = args
+    return len(extract_records(full, FLAGS))
 
 
 def list_fast5(root_folder, recursive=True, test_number=None):
@@ -73,10 +92,8 @@ def list_fast5(root_folder, recursive=True, test_number=None):
     return files[:test_number] if test_number else files
 
 
-def extract(FLAGS, rank=0, world=1):
-    """extract_sig_ref.py:31-90.  In a sharded run (one process per GPU) every rank extracts its own share of the
-    file list, file k -> rank k mod world, with its own worker pool -- the counterpart of the reference's
-    Pool(cpu_count()) (:58-60, :81) spread over the ranks instead of serialised on rank 0."""
+def prepare_folders(FLAGS, rank=0, world=1):
+    """extract_sig_ref.py:43-56: raw/ reference/ log/ under the output folder, and the extraction log."""
     root_folder, out_folder = FLAGS.input_dir, FLAGS.output_dir
     if not os.path.isdir(root_folder):
         raise IOError("Input directory does not found.")
@@ -87,6 +104,14 @@ def extract(FLAGS, rank=0, world=1):
     for d in (FLAGS.raw_folder, FLAGS.ref_folder, FLAGS.log_folder):
         os.makedirs(d, exist_ok=True)
     set_logger(os.path.join(FLAGS.log_folder, "extract.log" if world == 1 else "extract.rank%d.log" % rank))
+
+
+def extract(FLAGS, rank=0, world=1):
+    """extract_sig_ref.py:31-90.  In a sharded run (one process per GPU) every rank extracts its own share of the
+    file list, file k -> rank k mod world, with its own worker pool -- the counterpart of the reference's
+    Pool(cpu_count()) (:58-60, :81) spread over the ranks instead of serialised on rank 0."""
+    root_folder = FLAGS.input_dir
+    prepare_folders(FLAGS, rank, world)
     threads = FLAGS.threads if getattr(FLAGS, "threads", 0) else max(1, cpu_count() // max(world, 1))
     files = list_fast5(root_folder, getattr(FLAGS, "recursive", True), getattr(FLAGS, "test_number", None))[rank::max(world, 1)]
     if threads > 1 and len(files) > 1:

@@ -355,6 +355,48 @@ def read_fast5(path):
     return out
 
 
+def read_fast5_native(path, reverse=False):
+    """The same records through the native reader of libchiron_amd.so (csrc/fast5.cpp: file image, B-tree walk and zlib
+    inflate in C++, no GIL): -> list of {suffix, signal (float32 ndarray, reversed when `reverse`), read_id, fastq}.
+    This is the reader of the hot path (`chiron call` on fast5 input); the Python classes above remain for
+    what the hot path does not need (channel attributes for the pA conversion, arbitrary datasets) and as its cross-check."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    st = lib.chiron_fast5_open(path.encode() if isinstance(path, str) else path, C.byref(h))
+    if st != _lib.OK:
+        raise Fast5FormatError(lib.chiron_last_error().decode("utf-8", "replace"))
+    try:
+        out = []
+        suffix, rid = C.create_string_buffer(256), C.create_string_buffer(256)
+        for i in range(lib.chiron_fast5_read_count(h)):
+            n, fq = C.c_int64(), C.c_int64()
+            if lib.chiron_fast5_read_info(h, i, suffix, 256, rid, 256, C.byref(n), C.byref(fq)) != _lib.OK:
+                raise Fast5FormatError(lib.chiron_last_error().decode("utf-8", "replace"))
+            sig = np.empty(n.value, dtype=np.float32)
+            if lib.chiron_fast5_signal(h, i, sig.ctypes.data_as(C.c_void_p), n.value, 1 if reverse else 0) != _lib.OK:
+                raise Fast5FormatError(lib.chiron_last_error().decode("utf-8", "replace"))
+            fastq = ""
+            if fq.value > 0:
+                buf = C.create_string_buffer(fq.value + 1)
+                if lib.chiron_fast5_fastq(h, i, buf, fq.value + 1) == _lib.OK:
+                    fastq = buf.value.decode("utf-8", "replace")
+            out.append({"suffix": suffix.value.decode("utf-8", "replace"), "signal": sig,
+                        "read_id": rid.value.decode("utf-8", "replace"), "fastq": fastq})
+        return out
+    finally:
+        lib.chiron_fast5_close(h)
+
+
+def write_signal_text(path, signal, delimiter="\n"):
+    """extract_sig_ref.py:122-123 for integer DAC counts: delimiter.join(str(v) for v in signal), natively."""
+    import ctypes as C
+    from . import _lib
+    sig = np.ascontiguousarray(signal, dtype=np.float32)
+    _lib.check(_lib.load().chiron_write_signal_text(path.encode(), sig.ctypes.data_as(C.c_void_p), sig.shape[0], delimiter.encode()))
+
+
 def read_raw_signal(path):
     recs = read_fast5(path)
     if not recs:

@@ -56,16 +56,19 @@ def gather_results(output_dir, extension="fastq", merged_name="merged"):
     return out_path, len(names)
 
 
-def run_sharded(FLAGS, basecall_fn, dist=None):
+def run_sharded(FLAGS, basecall_fn, dist=None, partition=True):
     """One process per GPU.  basecall_fn(FLAGS, file_list) handles this rank's reads.
-    `dist` is torch.distributed (already initialised) or None for a single process."""
+    `dist` is torch.distributed (already initialised) or None for a single process.  partition=False: the caller has
+    already assigned this rank its inputs (the direct fast5 path partitions the fast5 files themselves)."""
     from . import eval as chiron_eval
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
-    files, file_dir = chiron_eval.list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
-    files = [f for f in files if f.endswith(".signal") or f.endswith(".fast5")]
-    sizes = {f: os.path.getsize(os.path.join(file_dir, f)) for f in files}
-    mine = partition_reads(files, world, rank, sizes)
+    mine = None
+    if partition:
+        files, file_dir = chiron_eval.list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
+        files = [f for f in files if f.endswith(".signal") or f.endswith(".fast5")]
+        sizes = {f: os.path.getsize(os.path.join(file_dir, f)) for f in files}
+        mine = partition_reads(files, world, rank, sizes)
     out = basecall_fn(FLAGS, mine)
     if dist is not None:
         dist.barrier()

@@ -53,7 +53,13 @@ def read_signal(file_path, normalize=None):
 def read_signal_fast5(fast5_path, normalize=None):
     """chiron_input.py:541-555 (statistics over the UNIQUE values, as the reference does)."""
     from . import fast5
-    signal = np.asarray(fast5.read_raw_signal(fast5_path))
+    try:
+        recs = fast5.read_fast5_native(fast5_path)          # csrc/fast5.cpp (B-tree walk + inflate without the GIL)
+        if not recs:
+            raise fast5.Fast5FormatError("no raw signal in %s" % fast5_path)
+        signal = recs[0]["signal"]
+    except ImportError:                                     # library not built: the Python reader gives the same samples
+        signal = np.asarray(fast5.read_raw_signal(fast5_path))
     if signal.shape[0] == 0:
         return signal.astype(np.float32)
     uniq = np.unique(signal)

@@ -234,6 +234,18 @@ chiron_status chiron_assemble(const uint8_t* bases, const int64_t* seg_off, int6
                               int32_t kernal, double error_rate, double jump_step_ratio, double* counts, double* qs_sum,
                               int64_t cap, int64_t* out_len);
 
+/* One read from its decoded windows to its files (chiron_eval.py:446-462 + write_output :176-228) in one call that never
+ * enters the interpreter: index2base of every window, the vote above, np.argmax (:457), qs (:152-174; seg_qs = NULL or
+ * fastq = 0: no quality, FASTA), then result_path = "@name\nSEQ\n+\nQUAL\n" (FASTQ) or ">name\nSEQ" (FASTA, no final
+ * newline; rna != 0 writes U for T in the consensus, :204-205) and -- unless segments_path is NULL (--concise) --
+ * ">name<k>\nSEGMENT\n" per window.  *consensus_len receives len(SEQ) (the caller writes meta/<name>.meta from it) and
+ * consensus_out [consensus_cap], when given, SEQ itself (no terminator; the decoded base count is always enough room).
+ * The folders must exist.  Equal, byte for byte, to the Python writers of chiron_amd/eval.py (tests).               */
+chiron_status chiron_finish_read(const uint8_t* bases, const int64_t* seg_off, int64_t n_seg, const double* seg_qs,
+                                 int32_t kernal, double error_rate, double jump_step_ratio, const char* name,
+                                 const char* result_path, const char* segments_path, int32_t fastq, int32_t rna,
+                                 char* consensus_out, int64_t consensus_cap, int64_t* consensus_len);
+
 /* One displacement of the vote above: where `cur` starts relative to the start of `prev` (the return value of
  * glue_kernal / stick_kernal / simple_assembly_kernal; for the simple kernel *log_px receives its second return
  * value, the score of the chosen offset; 0 otherwise; log_px may be NULL).                                       */
@@ -264,6 +276,29 @@ chiron_status chiron_consensus_device(int32_t device_id, const uint8_t* bases, c
  * CHIRON_ERR_INVALID (the reference raises ValueError); more than cap values -> CHIRON_ERR_OVERFLOW.
  * Pure host code: callable without a GPU and from several threads at once (it does not touch Python). */
 chiron_status chiron_parse_signal_text(const char* text, size_t len, float* out, size_t cap, size_t* n_out);
+
+/* fast5 (HDF5) reader without libhdf5 / h5py: what chiron/utils/extract_sig_ref.py:149-193 (extract_file for single-read
+ * files: the first group under /Raw/Reads; extract_file_v2 for multi-read files: one read per top-level group, sorted by
+ * name) takes from a file -- raw signal, read_id attribute, reference FASTQ / FASTA if present.  Replaces, together with
+ * chiron_input.py:541-555 read_signal_fast5, the extract -> `.signal` text -> read_signal round trip of `chiron call`
+ * (SURVEY 8(f)1).  Host code (zlib for the deflate filter): no GPU, thread-safe, every handle owns its file image.
+ * An unsupported or damaged file gives CHIRON_ERR_INVALID with the reason in chiron_last_error(); the caller logs and
+ * skips it, like the reference (extract_sig_ref.py:97-117).                                                        */
+typedef struct chiron_fast5 chiron_fast5;
+chiron_status chiron_fast5_open(const char* path, chiron_fast5** out);
+void chiron_fast5_close(chiron_fast5* f);
+int32_t chiron_fast5_read_count(const chiron_fast5* f);
+/* read i: suffix ("" for a single-read file, the read's group name in a multi-read file: the .signal name is
+ * <file stem><suffix>, extract_sig_ref.py:128-144), read_id, number of samples, length of the reference text (0: none) */
+chiron_status chiron_fast5_read_info(const chiron_fast5* f, int32_t i, char* suffix, size_t suffix_cap, char* read_id,
+                                     size_t id_cap, int64_t* n_samples, int64_t* fastq_len);
+/* the raw signal of read i as float32 (np.float32 of the DAC counts, chiron_input.py:536); reverse != 0 stores it
+ * back to front (RNA: extract_sig_ref.py:165 / chiron_input.py:269-272) */
+chiron_status chiron_fast5_signal(const chiron_fast5* f, int32_t i, float* out, int64_t cap, int32_t reverse);
+chiron_status chiron_fast5_fastq(const chiron_fast5* f, int32_t i, char* out, int64_t cap);
+/* extract_sig_ref.py:122-123: delimiter.join(str(v) for v in raw_signal) written to `path` for integer-valued samples
+ * (what `chiron call` extracts: unit = False, entry.py:36); a non-integer sample is refused (CHIRON_ERR_INVALID). */
+chiron_status chiron_write_signal_text(const char* path, const float* v, int64_t n, const char* delimiter);
 
 /* CRC-32C (Castagnoli) of a byte range: the checksum TF's tensor-bundle checkpoints record per tensor
  * (BundleEntryProto.crc32c holds its masked form; tensor_bundle.cc verifies it in Saver.restore, chiron_eval.py:276).

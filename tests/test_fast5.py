@@ -147,3 +147,84 @@ def test_extraction_shards_across_ranks(tmp_path):
     three = tmp_path / "three"
     assert sum(extract.extract(flags(three, test_number=3), rank=r, world=2) for r in range(2)) == 3
     assert len(extract.list_fast5(str(inp), True)) == 8 and len(extract.list_fast5(str(inp), False)) == 5
+
+
+def test_native_reader_equals_the_python_reader_on_every_fixture(tmp_path):
+    """csrc/fast5.cpp (chiron_fast5_*: the reader of the direct `chiron call` path) against fast5.py on
+    the reference's five example files (old-style groups, chunked + deflate int16 signal: sample counts and SHA-256 of the
+    reference's own raw/readN.signal), on multi-read files written by tests/h5_writer.py (contiguous and chunked +
+    deflate, with and without a reference FASTQ), reversed (RNA), and on damaged input (reason reported, nothing
+    crashes)."""
+    import hashlib
+    import json
+    import h5_writer
+    ex = os.path.join(GOLDEN, "example_dna")
+    digest = json.load(open(os.path.join(ex, "raw_digest.json")))
+    for name, d in digest.items():
+        p = os.path.join(ex, name + ".fast5")
+        py, nat = fast5.read_fast5(p), fast5.read_fast5_native(p)
+        assert len(py) == len(nat) == 1 and nat[0]["suffix"] == "" and nat[0]["signal"].dtype == np.float32
+        assert np.array_equal(np.asarray(py[0]["signal"]).astype(np.float32), nat[0]["signal"])
+        assert nat[0]["signal"].size == d["samples"]
+        assert hashlib.sha256(nat[0]["signal"].astype("<i2").tobytes()).hexdigest() == d["sha256_int16le"]
+        assert py[0]["read_id"] == nat[0]["read_id"] and py[0]["fastq"] == nat[0]["fastq"]
+        assert np.array_equal(fast5.read_fast5_native(p, reverse=True)[0]["signal"], nat[0]["signal"][::-1])
+    rng = np.random.RandomState(0)
+    for chunk in (None, 1000, 7):
+        reads = [("read_%d" % k, "id-%d" % k, rng.randint(-300, 1200, size=n).astype(np.int16), ("@x\nACGT\n+\n!!!!" if k % 2 else None))
+                 for k, n in enumerate((5000, 1, 12345))]
+        p = str(tmp_path / ("multi_%s.fast5" % chunk))
+        h5_writer.write_multi_read_fast5(p, reads, chunk=chunk)
+        py, nat = fast5.read_fast5(p), fast5.read_fast5_native(p)
+        assert [r["suffix"] for r in nat] == ["read_0", "read_1", "read_2"] == [r["suffix"] for r in py]
+        for a, b, (_, rid, sig, fq) in zip(py, nat, reads):
+            assert np.array_equal(b["signal"], sig.astype(np.float32)) and np.array_equal(np.asarray(a["signal"]), sig)
+            assert b["read_id"] == rid == a["read_id"] and b["fastq"] == (fq or "") == a["fastq"]
+    # damaged input: an error with a reason, never a crash
+    good = open(os.path.join(ex, "read1.fast5"), "rb").read()
+    bad = tmp_path / "bad.fast5"
+    for blob in (b"", b"not hdf5 at all", good[:100], good[:5000], good[:len(good) // 2],
+                 good[:8] + bytes([7]) + good[9:], good[:2048] + bytes(len(good) - 2048)):
+        bad.write_bytes(blob)
+        with pytest.raises(fast5.Fast5FormatError):
+            fast5.read_fast5_native(str(bad))
+    with pytest.raises(fast5.Fast5FormatError):
+        fast5.read_fast5_native(str(tmp_path / "missing.fast5"))
+    # a flipped byte inside a deflate stream
+    h5_writer.write_multi_read_fast5(str(bad), [("r", "i", rng.randint(0, 900, size=4000).astype(np.int16), None)], chunk=4000)
+    blob = bytearray(bad.read_bytes())
+    blob[300] ^= 0xFF
+    bad.write_bytes(bytes(blob))
+    try:
+        got = fast5.read_fast5_native(str(bad))
+        assert got[0]["signal"].size == 4000          # the flip hit padding: still a valid file
+    except fast5.Fast5FormatError:
+        pass
+
+
+def test_signal_text_writer_and_extract_records(tmp_path):
+    """chiron_write_signal_text == delimiter.join(str(v) for v in raw) (extract_sig_ref.py:122-123) for integer samples,
+    negative values and the empty signal included; a non-integer sample is refused.  extract.extract_records returns the
+    samples it wrote (what the direct path windows) and the text parses back to them."""
+    sig = np.array([487, -3, 0, 32767, -32768, 12], dtype=np.int16)
+    for delim in ("\n", " "):
+        p = str(tmp_path / "a.signal")
+        fast5.write_signal_text(p, sig.astype(np.float32), delim)
+        assert open(p).read() == delim.join(str(v) for v in sig.tolist())
+    fast5.write_signal_text(p, np.zeros(0, dtype=np.float32))
+    assert open(p).read() == ""
+    from chiron_amd._lib import ChironError
+    with pytest.raises(ChironError):
+        fast5.write_signal_text(p, np.array([1.5], dtype=np.float32))
+
+    class F(object):
+        mode, unit, idname, delimiter = "dna", False, False, "\n"
+        raw_folder, ref_folder = str(tmp_path / "raw"), str(tmp_path / "reference")
+    os.makedirs(F.raw_folder)
+    os.makedirs(F.ref_folder)
+    recs = extract.extract_records(F5, F)
+    assert len(recs) == 1 and recs[0][0] == "read1" and recs[0][1].dtype == np.float32
+    assert np.array_equal(signal_io.read_signal(os.path.join(F.raw_folder, "read1.signal")), recs[0][1])
+    assert np.array_equal(recs[0][1], signal_io.read_signal(SIG))
+    F.mode = "rna"
+    assert np.array_equal(extract.extract_records(F5, F)[0][1], recs[0][1][::-1])

@@ -1169,6 +1169,36 @@ def test_chiron_call_cli_on_fast5_folder(tmp_path):
     entry.main(["call", "-i", str(one), "-o", out2, "-m", model, "-p", "dna-pre", "-b", "100", "--synthetic-weights"])
     fq2 = open(os.path.join(out2, "result", "read1.fastq")).read().split("\n")
     assert fq2[0] == "@read1" and len(fq2[1]) == len(fq2[3]) > 0
+    # the run above took the DIRECT path (native fast5 reader -> windows; raw/*.signal written but never parsed
+    # back).  The reference's two passes (extract everything, then parse raw/*.signal: --via-signal-files) must give the same
+    # tree byte for byte -- with a multi-read fast5 (extract_file_v2: one read per top-level group) next to the five
+    # single-read files, in RNA mode too (signal reversed, T -> U).
+    import h5_writer
+    rng = np.random.RandomState(3)
+    sig_a = ca.synthetic_signal(2, 9000, seed=77).astype(np.int16)
+    h5_writer.write_multi_read_fast5(str(inp / "multi.fast5"), [("read_aa", "id-a", sig_a[0], "@x\nACGT\n+\n!!!!"),
+                                                                  ("read_bb", "id-b", sig_a[1][:4321], None)], chunk=1000)
+    (inp / "broken.fast5").write_bytes(b"\x89HDF\r\n\x1a\n" + bytes(200))
+    for mode in ("dna", "rna"):
+        trees = []
+        for via in (False, True):
+            o = str(tmp_path / ("cmp_%s_%d" % (mode, via)))
+            argv = ["call", "-i", str(inp), "-o", o, "-m", model, "-p", "dna-pre", "-b", "100", "--beam", "0", "--synthetic-weights",
+                    "--mode", mode] if mode == "dna" else \
+                   ["call", "-i", str(inp), "-o", o, "-m", model, "-b", "100", "-l", "400", "-j", "390", "--beam", "0", "--synthetic-weights",
+                    "--mode", mode]
+            entry.main(argv + (["--via-signal-files"] if via else []))
+            trees.append(o)
+        for sub_ in ("raw", "result", "segments", "reference"):
+            names = sorted(os.listdir(os.path.join(trees[0], sub_)))
+            assert names == sorted(os.listdir(os.path.join(trees[1], sub_))), (mode, sub_)
+            if sub_ == "raw":
+                assert "multiread_aa.signal" in names and "multiread_bb.signal" in names and len(names) == 7
+            for n_ in names:
+                assert open(os.path.join(trees[0], sub_, n_), "rb").read() == open(os.path.join(trees[1], sub_, n_), "rb").read(), (mode, sub_, n_)
+        assert "broken.fast5" in open(os.path.join(trees[0], "log", "extract.log")).read()
+        if mode == "rna":
+            assert "U" in open(os.path.join(trees[0], "result", "read1.fastq")).read().split("\n")[1]
 
 
 def test_sharded_call_equals_single_process(tmp_path):

@@ -298,7 +298,9 @@ def test_read_collector_orders_pieces_by_window_index():
     assert col.add_batch(b0, r0, True) == []
     done = col.add_batch(b1, r1, True)
     assert len(done) == 1
-    name, reads, qs_list, meta = done[0]
+    name, flat, seg_len, qs_list, meta = done[0]
+    reads = ce.split_flat(flat, seg_len)
+    assert flat.dtype == np.uint8 and seg_len.tolist() == [1] * 9
     assert [int(r[0]) for r in reads] == [i % 4 for i in range(9)]
     assert qs_list.ravel().tolist() == list(map(float, range(9)))
 
@@ -370,10 +372,61 @@ def test_packer_collector_round_trip_random_streams():
             res = DecodeResult(st, np.zeros((B, 1), np.float32), b.x[:, :1].copy(), None)
             done += col.add_batch(b, res, True)
         assert sorted(d[0] for d in done) == sorted(n for n, _ in reads)
-        for name, out_reads, qs_list, meta in done:
+        for name, flat, seg_len, qs_list, meta in done:
+            out_reads = ce.split_flat(flat, seg_len)
             n = dict(reads)[name]
             want = [u for u, (nm, k) in sorted(token.items(), key=lambda kv: kv[1][1]) if nm == name and u % 3 > 0]
             assert len(out_reads) == len(want), (trial, name)
             assert qs_list.ravel().tolist() == [float(u) for u in want]
             for rd, u in zip(out_reads, want):
                 assert [int(v) for v in rd] == [(u + p) % 4 for p in range(u % 3)]
+
+
+def test_native_finisher_writes_the_same_files_as_the_python_writers(built, tmp_path):
+    """chiron_finish_read (one GIL-free call: index2base, vote, argmax, qs, result/ + segments/ files) against finish_read
+    (the Python writers, chiron_eval.py:446-462 / :176-242) on random reads: FASTQ and FASTA, --concise, RNA (T -> U in the
+    consensus only), the glue / stick / simple kernels (chosen by jump : segment_len as get_assembler_kernal does), reads
+    of 0 / 1 / 2 windows, empty decodes inside a read, tied votes and quality sums that land on integer boundaries.  Every
+    result / segments file must be identical byte for byte, and the returned consensus too."""
+    rng = np.random.RandomState(123)
+
+    def flags(out, ext, concise, mode, jump, python_finish):
+        class F(object):
+            pass
+        F.output, F.extension, F.concise, F.mode, F.jump, F.segment_len = out, ext, concise, mode, jump, 400
+        F.batch_size, F.start, F.input, F.model, F.python_finish = 100, 0, "in/", "m", python_finish
+        for sub in ("result", "segments", "meta"):
+            os.makedirs(os.path.join(out, sub), exist_ok=True)
+        return F
+    case = 0
+    for ext in ("fastq", "fasta"):
+        for concise in (False, True):
+            for mode in ("dna", "rna"):
+                for jump in (390, 400, 30):                  # glue, stick, simple
+                    for n_seg in (0, 1, 2, 3, 40):
+                        case += 1
+                        base_len = 8 if jump == 30 else 30
+                        truth = rng.randint(0, 4, size=n_seg * 6 + base_len + 8)
+                        segs = []
+                        for k in range(n_seg):               # overlapping windows of one underlying sequence, with errors
+                            a = 6 * k if jump != 400 else base_len * k % max(1, truth.size - base_len)
+                            sg = truth[a:a + base_len].copy()
+                            flip = rng.rand(sg.size) < 0.1
+                            sg[flip] = rng.randint(0, 4, size=int(flip.sum()))
+                            segs.append(sg[: rng.randint(1, sg.size + 1)] if rng.rand() < 0.2 else sg)
+                        seg_len = np.asarray([len(s_) for s_ in segs], dtype=np.int64)
+                        flat = np.concatenate(segs).astype(np.uint8) if segs else np.zeros(0, dtype=np.uint8)
+                        qs_list = np.round(rng.uniform(0, 6, size=(n_seg, 1)), rng.randint(0, 3))     # round numbers: integer boundaries
+                        outs = []
+                        for python_finish in (True, False):
+                            F = flags(str(tmp_path / ("c%d_%d" % (case, python_finish))), ext, concise, mode, jump, python_finish)
+                            cons = ce.finish_read_flat("read_x.signal", flat, seg_len, qs_list, F, 0.0, 0.0)
+                            outs.append((F.output, cons))
+                        assert outs[0][1] == outs[1][1], case
+                        for sub in ("result",) + (() if concise else ("segments",)):
+                            a = open(os.path.join(outs[0][0], sub, "read_x." + ext), "rb").read()
+                            b = open(os.path.join(outs[1][0], sub, "read_x." + ext), "rb").read()
+                            assert a == b, (case, sub, ext, concise, mode, jump, n_seg)
+                        assert os.path.exists(os.path.join(outs[1][0], "meta", "read_x.meta")) != concise
+                        if concise:
+                            assert os.listdir(os.path.join(outs[1][0], "segments")) == []

@@ -37,7 +37,7 @@ def main():
     import bench
     out = {"_kernel_sources_sha256_16": bench.kernel_sources_digest(),
            "_note": "mean per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction)",
-           "_command": "tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 3 --rounds 1 --warmup 1 --slots 1 --no-cpu-baseline --no-f16"}
+           "_command": "tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 3 --rounds 1 --host-rounds 0 --warmup 1 --slots 1 --no-cpu-baseline --no-f16"}
     for f, c in acc.items():
         m = {k: sum(v) / len(v) for k, v in c.items()}
         rec = {"launches_sampled": len(c.get("FETCH_SIZE", c.get("SQ_WAVE_CYCLES", [])))}

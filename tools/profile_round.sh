@@ -19,7 +19,7 @@ cp "$OUT/${R}_pmc.json" "profiles/${R}_pmc.json"
 # 2. kernel trace of the bench command with one batch in flight (the per-kernel table) + its bench line
 #    (--no-f16: the fp16 / split side runs of the default command would put their kernels into the same trace)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o slots1 -- \
-  python bench.py --slots 1 --steps 5 --rounds 1 --warmup 2 --no-f16 > "$OUT/bench_slots1.json" 2> "$OUT/bench_slots1.err"
+  python bench.py --slots 1 --steps 5 --rounds 1 --host-rounds 0 --warmup 2 --no-f16 > "$OUT/bench_slots1.json" 2> "$OUT/bench_slots1.err"
 cp "$OUT"/prof/slots1_kernel_stats.csv "$OUT/${R}_kernel_stats_slots1.csv" 2>/dev/null || \
   find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_kernel_stats_slots1.csv" \;
 
@@ -32,9 +32,15 @@ python tools/bench_configs.py > "$OUT/secondary.jsonl" 2> "$OUT/secondary.err"
 python tools/bench_configs.py f16 >> "$OUT/secondary.jsonl" 2>> "$OUT/secondary.err"
 python tools/bench_configs.py split >> "$OUT/secondary.jsonl" 2>> "$OUT/secondary.err"
 
-# 5. end to end through the host pipeline (512 synthetic reads x 100k samples, .signal files -> FASTQ tree)
-python tools/e2e_bench.py 512 0 > "$OUT/e2e.txt" 2> "$OUT/e2e.err"
-python tools/e2e_bench.py 512 30 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+# 5. end to end through the host pipeline (synthetic reads x 100k samples -> FASTQ tree): .signal input, fast5 input on the
+#    direct path, fast5 through the reference's two passes; greedy and the default beam 30; behind the fp16 engine at batch 4096
+python tools/e2e_bench.py 512 0 - fp32 1100 signal > "$OUT/e2e.txt" 2> "$OUT/e2e.err"
+python tools/e2e_bench.py 512 0 - fp32 1100 fast5 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+python tools/e2e_bench.py 512 0 - fp32 1100 fast5-via-signal >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+python tools/e2e_bench.py 512 30 - fp32 1100 signal >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+python tools/e2e_bench.py 512 30 - fp32 1100 fast5 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+python tools/e2e_bench.py 2048 0 - fp16 4096 signal >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+python tools/e2e_bench.py 2048 0 - fp16 4096 fast5 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
 
 # 6. fp16 engine at configs[4], kernel trace
 bash tools/f16_profile.sh > "$OUT/f16_kernels.txt" 2> "$OUT/f16_kernels.err"
