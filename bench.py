@@ -72,11 +72,16 @@ def make_batches(n_batches, rank):
 
 # profiling bucket of the engine (chiron_engine_profile) -> kernel symbol(s) in a rocprofv3 trace; template arguments of
 # gemm_f32_dma_kernel are <ZOUT, RES, chunks per K-segment, K tail, mode (0 fp32, 1 f16, 2 split)>
+_REC_FORM = os.environ.get("CHIRON_LSTM_WIDE", "2")     # engine.hip CHIRON_LSTM_WIDE_DEFAULT
+_STREAM32 = os.environ.get("CHIRON_NO_STREAM32") is None
 BUCKET_SYMBOL = {
-    "lstm_recurrence": "lstm_kernel<1>",
-    "conv_dma": "gemm_f32_dma_kernel<false, false, 8, false, 0>",          # conv2a (K=256) and conv2c+branch1 (K=512) of res_layer2/3
+    # the recurrence: lstm32w2_kernel = 16 rows per workgroup on v_mfma_f32_16x16x4_f32, ONE workgroup per 16-row group and
+    # direction (138 for batch 1100: 54 % of the CUs); lstm_kernel<1> = the 4-row form (CHIRON_LSTM_WIDE=0)
+    "lstm_recurrence": {"0": "lstm_kernel<1>", "1": "lstm32w_kernel", "2": "lstm32w2_kernel"}.get(_REC_FORM, "lstm32w2_kernel"),
+    "conv_dma": "gemm_f32_dma_kernel<false, false, 8, false, 0>",          # conv2c+branch1 (K=512) of res_layer2/3 (and conv2a with CHIRON_NO_STREAM32)
+    "conv2a": "conv1x1_f32_stream_kernel<false>" if _STREAM32 else "gemm_f32_dma_kernel<false, false, 8, false, 0>",   # conv2a (K=256) of res_layer2/3
     "conv_wino": "wino_conv3_f4_kernel",                                    # conv2b of res_layer2/3, Winograd F(4,3) (T % 4 == 0)
-    "conv_res": "gemm_f32_dma_kernel<false, true, 8, false, 0>",            # conv2c + signal branch of res_layer1
+    "conv_res": "conv1x1_f32_stream_kernel<true>" if _STREAM32 else "gemm_f32_dma_kernel<false, true, 8, false, 0>",   # conv2c + signal branch of res_layer1
     "lstm_proj0_dma": "gemm_f32_dma_kernel<true, false, 8, false, 0>",      # x-projection of layer 0 (K = 256)
     "lstm_proj_dma": "gemm_f32_dma_kernel<true, false, 7, true, 0>",        # x-projections of layers 1, 2 (K = 200)
 }
@@ -168,11 +173,14 @@ def main():
             consensus_bases[0] += int(cons[0].shape[1])
 
     def step(i, pending):
+        """collect the slot's finished batch, hand the slot its next batch at once, THEN do the host side of the finished one
+        (collect() returns copies: the slot's buffers are free again) -- the stream never waits for the host's vote"""
         slot = i % args.slots
-        if pending[slot] is not None:
-            consume(eng.collect(slot), pending[slot])
+        res, which = (eng.collect(slot), pending[slot]) if pending[slot] is not None else (None, None)
         eng.submit(slot, x_dev[i % n_distinct], s_dev[i % n_distinct], beam_width=0, want_prob=True)
         pending[slot] = i % n_distinct
+        if res is not None:
+            consume(res, which)
 
     def drain(pending):
         for slot in range(args.slots):
@@ -221,11 +229,13 @@ def main():
 
         def host_step(i, pending):
             slot = i % args.slots
-            if pending[slot] is not None:
-                consume(eng.collect(slot), pending[slot])
             ev, ln = signal_io.window_signal(raw[i % n_distinct], 0, JUMP, SEG_LEN)      # chiron_input.py:253-292
-            eng.submit(slot, ev[:BATCH], ca.seq_len_for_engine(ln[:BATCH], eng.ratio), beam_width=0, want_prob=True)
+            sl = ca.seq_len_for_engine(ln[:BATCH], eng.ratio)
+            res, which = (eng.collect(slot), pending[slot]) if pending[slot] is not None else (None, None)
+            eng.submit(slot, ev[:BATCH], sl, beam_width=0, want_prob=True)
             pending[slot] = i % n_distinct
+            if res is not None:
+                consume(res, which)
 
         for i in range(args.warmup):
             host_step(i, pending)
@@ -291,6 +301,11 @@ def main():
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 of a separate rocprofv3 --pmc pass",
+                    # a kernel that does not fill the chip by construction: the wide recurrence launches one 8-wave workgroup per
+                    # 16-row group and direction; the other CUs run the other batches' kernels meanwhile (three in flight)
+                    "workgroups": (2 * ((BATCH + 15) // 16)) if dom_key == "lstm_recurrence" and _REC_FORM != "0" else None,
+                    "frac_of_the_cus_it_occupies": (round(achieved / PEAK_F32_MFMA_TFLOPS * 256.0 / min(256, 2 * ((BATCH + 15) // 16)), 4)
+                                                    if dom_key == "lstm_recurrence" and _REC_FORM != "0" else None),
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
                     "flops_per_launch": dom["flops"] / dom["launches"],
@@ -310,7 +325,7 @@ def main():
                 if pc["hbm_bytes_per_launch"]:
                     per_bucket[k]["hbm_gbps_pmc"] = round(pc["hbm_bytes_per_launch"] / (stats[k]["total_ms"] / stats[k]["launches"] * 1e-3) / 1e9, 1)
         roofline["pmc"] = pmc_counters(dom_symbol)
-        fam = [s for k, s in stats.items() if k.startswith("conv_") or k.startswith("lstm_proj")]
+        fam = [s for k, s in stats.items() if k.startswith("conv") or k.startswith("lstm_proj")]
         gemm_family = {"launches_per_batch": sum(s["launches"] for s in fam) / 3.0,
                        "tflops": round(sum(s["flops"] for s in fam) / (sum(s["total_ms"] for s in fam) * 1e-3) / 1e12, 2),
                        "ms_per_batch": round(sum(s["total_ms"] for s in fam) / 3.0, 3)}

@@ -117,7 +117,7 @@ extern "C" chiron_status chiron_weights_size(const chiron_model_desc* d, size_t*
 // engine state
 // ----------------------------------------------------------------------------------------------
 // Default form of the fp32 recurrence (DESIGN 3.2 has the same-box A/B figures behind the choice)
-#define CHIRON_LSTM_WIDE_DEFAULT 0
+#define CHIRON_LSTM_WIDE_DEFAULT 2
 
 struct DevBuf {
   void* p = nullptr;
@@ -221,12 +221,13 @@ struct chiron_engine {
   chiron_engine_opts opts;
   int L = 0, T = 0, C = 0, H = 0, K = 0;
   int maxB = 0, BP = 0;
+  bool stream32 = true;           // fp32: 1 x 1 convolutions on the weight-stationary streaming kernel (CHIRON_NO_STREAM32=1: gemm.hip, A/B switch)
   bool stream16 = true;           // f16: 1 x 1 convolutions on the streaming kernel (CHIRON_NO_STREAM16=1: gemm.hip, A/B switch)
   bool lstm16_pair = false;       // f16 fused recurrence: two 16-row groups per workgroup (A/B switch)
   bool lstm16_fused = false;      // f16: x-projection inside the recurrence (whole 16-row groups that fill the CUs)
   bool lstm16_narrow = false;     // A/B switch: f16 recurrence on 4-row workgroups only
   bool lstm_fixed_roles = false;  // A/B switch: light role always on wave 6
-  bool lstm_narrow = false;       // A/B switch: fp32 recurrence on the 4-row kernels (lstm_kernel) instead of lstm32w_kernel
+  int lstm_form = 0;              // fp32 recurrence: 0 = 4-row kernels (lstm_kernel), 1 = lstm32w_kernel, 2 = lstm32w2_kernel
   bool lstm_paired = false;  // fp32 recurrence: 14-wave workgroups for the part of a batch that fits one resident round
   bool bn_batch = false;  // desc.bn_mode == CHIRON_BN_BATCH
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
@@ -841,11 +842,13 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   // fp32 recurrence form: CHIRON_LSTM_WIDE=1 -> lstm32w_kernel (16 rows per workgroup), =0 -> lstm_kernel (4 rows); read once here
   {
     const char* wv = getenv("CHIRON_LSTM_WIDE");
-    e->lstm_narrow = wv ? atoi(wv) == 0 : !CHIRON_LSTM_WIDE_DEFAULT;
+    e->lstm_form = wv ? atoi(wv) : CHIRON_LSTM_WIDE_DEFAULT;
+    if (e->lstm_form < 0 || e->lstm_form > 2) e->lstm_form = CHIRON_LSTM_WIDE_DEFAULT;
   }
   e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;
   e->lstm16_pair = getenv("CHIRON_LSTM16_PAIR") != nullptr;
   e->stream16 = getenv("CHIRON_NO_STREAM16") == nullptr;
+  e->stream32 = getenv("CHIRON_NO_STREAM32") == nullptr;
   {
     // f16 engines run the x-projection inside the recurrence (lstm16f_kernel) from 64 sixteen-row workgroups up (B >= 512:
     // a workgroup alone on its CU takes 0.69 ms for T = 400 whatever the batch, the projection GEMMs + the 4-row recurrence
@@ -865,7 +868,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     chiron_engine_destroy(e);
     return st;
   }
-  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res", "conv1_pwl", "conv_wino", "lstm_proj0_dma"};
+  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res", "conv1_pwl", "conv_wino", "lstm_proj0_dma", "conv2a"};
   *out = e;
   return CHIRON_OK;
 }
@@ -898,7 +901,7 @@ extern "C" chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out
 // ----------------------------------------------------------------------------------------------
 // launch sequence
 // ----------------------------------------------------------------------------------------------
-enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES, PN_PWL, PN_WINO, PN_PROJ0 };
+enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES, PN_PWL, PN_WINO, PN_PROJ0, PN_CONV2A };
 
 struct Prof {
   chiron_engine* e;
@@ -934,6 +937,7 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
 
 // Segments are filled in ELEMENTS; the f16 kernels address in 4-byte units (see GemmParams::f16).
 static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
+  if (!e->f16 && !e->split && e->stream32 && launch_stream32(g, stream)) return true;   // fp32 256 -> 256 channel 1 x 1 convolutions
   if (e->split) g.f16 = 2;  // same 4-byte element units as fp32; only the content of the 128-byte blocks differs
   if (e->f16) {
     if (e->stream16 && launch_stream16(g, stream)) return true;   // 256 -> 256 channel 1 x 1 convolutions: streaming kernel
@@ -1116,7 +1120,8 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.out = bufA;
       g.ldo = b.c;
       {
-        Prof pr(e, s, PN_CONV, 2.0 * B * b.t_in * (double)b.c_in * b.c, 4.0 * B * b.t_in * (b.c_in + b.c));
+        // conv2a (K = c_in) has its own bucket: on the fp32 engine it runs on the streaming kernel (stream32.hip)
+        Prof pr(e, s, PN_CONV2A, 2.0 * B * b.t_in * (double)b.c_in * b.c, 4.0 * B * b.t_in * (b.c_in + b.c));
         ok &= launch(e, g, s->stream);
       }
       // conv2b
@@ -1208,7 +1213,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.wlight = lp.wlight;
     r.wwide = lp.wwide;
     r.wwide32 = lp.wwide32;
-    r.narrow32 = e->lstm_narrow ? 1 : 0;
+    r.form32 = e->lstm_form;
     r.narrow16 = e->lstm16_narrow ? 1 : 0;
     r.xsrc = nullptr;
     r.wxwide = nullptr;

@@ -99,6 +99,10 @@ bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel 
 // fp16 engine, 1 x 1 convolutions with 256 channels in and out (stream16.hip): weights in registers, activations streamed through
 // the LDS.  Takes GemmParams in ELEMENT units (before launch()'s conversion to 4-byte units); false: shape not covered.
 bool launch_stream16(const GemmParams& p, hipStream_t stream);
+// fp32 engine, 1 x 1 convolutions with 256 channels in and out (stream32.hip): the whole weight matrix in registers, activations
+// streamed through the LDS by producer waves.  false: shape not covered (the caller takes launch_gemm).
+bool launch_stream32(const GemmParams& p, hipStream_t stream);
+
 
 // 1 x 3 stride-1 convolution in Winograd F(2,3) form (wino.hip): fp32, channels-last, T even, C % 32 == 0, N % 64 == 0
 struct WinoParams {
@@ -126,7 +130,7 @@ struct LstmParams {
                          //   entry m = 4q + a, lane = kg*16 + gate*4 + j  ->  W_hh[k = 16q + 4kg + a][gate*H + 96 + j]
   const float* wwide32;  // fp32 wide form (lstm32w_kernel): [ndir][8 waves][4 tile slots][25 k-steps][64 lanes], lane = kq*16 + 4u + gate ->
                          //   W_hh[k = 4 ks + kq][gate*H + 4 tile + u], tile = 3 wave + slot (zero for the slots a wave does not use)
-  int narrow32;          // fp32: 1 = the 4-row kernels (lstm_kernel) instead of the wide form (CHIRON_LSTM_WIDE=0)
+  int form32;            // fp32: 0 = the 4-row kernels (lstm_kernel), 1 = lstm32w_kernel, 2 = lstm32w2_kernel (CHIRON_LSTM_WIDE)
   const void* wwide;     // f16 wide form: [ndir][8 waves][4 tile slots][7 k-steps][64 lanes][4 halves], lane = kq*16 + 4u + gate ->
                          //   W_hh[k = 16 ks + 4 kq + e][gate*H + 4 tile + u], tile = 3 wave + slot (zero past K or the wave's tiles)
   // f16, fused with the x-projection (lstm16f_kernel; xsrc == nullptr: z comes from the projection GEMM as above)

@@ -975,6 +975,171 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w_kernel(const LstmParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fp32 wide form, balanced (lstm32w2_kernel; CHIRON_LSTM_WIDE=2).  lstm32w_kernel gives wave 7 four of the 25 column tiles:
+// its SIMD carries 7 tiles x 25 k-steps x 32 cycles = 5600 matrix-pipe cycles per step and 7 cells of gate math, the others
+// 4800 and 6.  Here every wave owns THREE tiles (0 .. 23) and the 25th (units 96..99) is K-split:
+//   waves 0, 1, 2 each multiply 8 of its first 24 k-steps (partial 16 x 16 products, handed to wave 7 through LDS);
+//   wave 7 (whose SIMD partner, wave 3, takes no partial) adds the three partials, its own product of the LAST k-step and z,
+//   and does the tile's gate math.
+// The last k-step is k = 96..99 -- the units of that very tile -- so the step is split in two: k-steps 0..23 need only
+// h[0..95], which every wave has written before barrier A; wave 7 finishes tile 24 of the PREVIOUS step while the others
+// are already multiplying, writes h[96..99], barrier B, then everybody issues the 25th k-step.  Per SIMD: 156 MFMAs (5000
+// cycles) and 6 cells of gate math, wave 7's seventh overlapping the other SIMDs' products.
+// Same arithmetic per row as lstm32w_kernel for tiles 0..23; tile 24 sums its partial products in the fixed order
+// ((p0 + p1) + p2) + (p24 + z): agrees with the other forms to rounding, and a row's bits do not depend on its batch.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int W32_PK = 8;   // k-steps of tile 24 per partial wave (waves 0, 1, 2)
+
+__global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmParams p) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2 * HW32];
+  __shared__ __attribute__((aligned(16))) float xf[(W16_NW * 3 + 1) * W16_XF];
+  __shared__ __attribute__((aligned(16))) float part[3 * 256];    // [partial wave][lane][4 rows]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x % p.ndir;
+  const int g16 = blockIdx.x / p.ndir;
+  const int tile0 = 3 * wave;
+  const bool partial = wave < 3, owner24 = wave == W16_NW - 1;
+
+  float w[3][W32_KS], wp[W32_PK];
+  {
+    // a wave's own tiles: wave w, slots 0..2 of the fragment array; tile 24 = wave 7, slot 3
+    const float* wf = p.wwide32 + ((long)dir * W16_NW + wave) * W16_NT * W32_KS * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int ks = 0; ks < W32_KS; ++ks) w[n][ks] = wf[(n * W32_KS + ks) * 64];
+    const float* w24 = p.wwide32 + (((long)dir * W16_NW + 7) * W16_NT + 3) * W32_KS * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < W32_PK; ++j) wp[j] = partial ? w24[(W32_PK * wave + j) * 64] : (owner24 && j == 0 ? w24[24 * 64] : 0.f);
+  }
+  for (int i = tid; i < 2 * HW32; i += 64 * W16_NW) hbuf[i] = 0.f;
+
+  const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;
+  const int row = 4 * q + gp;
+  const int brow = g16 * 16 + row;
+  const int lenr = min(p.seq_len[brow], p.T);
+  int maxlen = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) maxlen = max(maxlen, min(p.seq_len[g16 * 16 + r], p.T));
+  __syncthreads();
+
+  const unsigned outw = p.ndir * p.H;
+  const unsigned zcols = 4 * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;
+  const unsigned zlane_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 4 * tile0 + u) * 4) * 4;   // + 64 bytes per tile
+  const unsigned z24_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 96 + u) * 4) * 4;
+  const unsigned ostep = p.BP * outw;
+  const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;   // + 4 per tile
+  const unsigned olane24 = brow * outw + dir * p.H + 96 + u;
+  const int hw = tile0 * 64 + u * 16 + row;                          // + 64 per tile
+  const int hw24 = 24 * 64 + u * 16 + row;
+  float* const xw = xf + wave * 3 * W16_XF + 4 * lane + 4 * q;
+  const float* const xr = xf + wave * 3 * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+  float* const xw24 = xf + W16_NW * 3 * W16_XF + 4 * lane + 4 * q;
+  const float* const xr24 = xf + W16_NW * 3 * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+
+  float c[3] = {0.f, 0.f, 0.f}, hprev[3] = {0.f, 0.f, 0.f};
+  float c24 = 0.f, hprev24 = 0.f;
+  f32x4 acc24 = {0.f, 0.f, 0.f, 0.f};   // wave 7: last k-step's product + z of the step being finished
+  int cur = 0;
+
+  // wave 7: tile 24 of step sp (its partial products are in `part`, acc24 / z24p in registers)
+  auto finish24 = [&](int sp, int buf, bool write_h) {
+    const f32x4* pp = reinterpret_cast<const f32x4*>(part) + lane;
+    f32x4 sum = pp[0] + pp[64];
+    sum = sum + pp[128];
+    *reinterpret_cast<f32x4*>(xw24) = sum + acc24;
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 gates = {xr24[0], xr24[4], xr24[8], xr24[12]};
+    const bool act = sp < lenr;
+    float hnew;
+    const float cn = lstm_cell(gates, c24, &hnew);
+    c24 = act ? cn : c24;
+    hprev24 = act ? hnew : hprev24;
+    if (write_h) hbuf[buf * HW32 + hw24] = hprev24;
+    const unsigned to = (dir == 0 || !act) ? sp : lenr - 1 - sp;
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + (to * ostep + olane24) * 4u) = act ? hnew : 0.f;
+  };
+
+  for (int s = 0; s < maxlen; ++s) {
+    const float* zs = p.z + (size_t)s * zstep;
+    f32x4 z4[3], z24 = {0.f, 0.f, 0.f, 0.f};
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z4[0]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(z4[1]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=v"(z4[2]) : "v"(zlane_b), "s"(zs) : "memory");
+    if (owner24) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z24) : "v"(z24_b), "s"(zs) : "memory");
+    // ---- wave 7 first completes tile 24 of the previous step: h[96..99] of that step is what the last k-step below needs
+    if (owner24 && s > 0) finish24(s - 1, cur, true);
+    // ---- k-steps 0 .. 23: h[0..95] of the previous step (complete since barrier A)
+    const float* hb = hbuf + cur * HW32 + lane;
+    // h is read eight k-steps at a time, the next eight in flight behind the current products (24 live values would put the
+    // kernel over 168 registers: two waves per SIMD at <= 168 leave room for a conv GEMM wave of another batch on the SIMD)
+    f32x4 acc[3], accp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 3; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float hv[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hv[0][j] = hb[j * 64];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      if (ch < 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[(ch + 1) & 1][j] = hb[(8 * (ch + 1) + j) * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ks = 8 * ch + j;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[ch & 1][j], w[n][ks], acc[n], 0, 0, 0);
+        if (partial && ch == wave) accp = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[ch & 1][j], wp[j], accp, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // barrier B: h[96..99] of the previous step is in place
+    // ---- the 25th k-step
+    const float h24 = hb[(W32_KS - 1) * 64];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(h24, w[n][W32_KS - 1], acc[n], 0, 0, 0);
+    if (owner24) {
+      acc24 = __builtin_amdgcn_mfma_f32_16x16x4f32(h24, wp[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(z24), "+v"(acc24) : : "memory");
+      acc24 = acc24 + z24;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z4[0]), "+v"(z4[1]), "+v"(z4[2]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+    const bool act = s < lenr;
+    const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(xw + n * W16_XF) = acc[n] + z4[n];
+    if (partial) reinterpret_cast<f32x4*>(part)[wave * 64 + lane] = accp;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const float* xs = xr + n * W16_XF;
+      const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};
+      float hnew;
+      const float cn = lstm_cell(gates, c[n], &hnew);
+      c[n] = act ? cn : c[n];
+      hprev[n] = act ? hnew : hprev[n];
+      hbuf[(cur ^ 1) * HW32 + hw + 64 * n] = hprev[n];
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + (to * ostep + olane + 4 * n) * 4u) = act ? hnew : 0.f;
+    }
+    cur ^= 1;
+    __syncthreads();   // barrier A: h[0..95] of this step and the partial products of tile 24 are in place
+  }
+  if (owner24 && maxlen > 0) finish24(maxlen - 1, cur, false);
+
+  for (int s = maxlen; s < p.T; ++s)
+    for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
+      const int r = i / p.H;
+      const int uu = i - r * p.H;
+      p.out[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = 0.f;
+    }
+}
+
 static int lstm_cu_count() { return current_device_cus(); }
 
 void launch_lstm(const LstmParams& p0, hipStream_t stream) {
@@ -1007,8 +1172,11 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
     if (groups > p.group0) hipLaunchKernelGGL(lstm16_kernel, dim3((groups - p.group0) * p.ndir), dim3(64 * LSTM_NW), 0, stream, p);
     return;
   }
-  if (p.wwide32 && !p.narrow32 && !p.paired) {   // the default: sixteen-row workgroups for every row of the padded batch
-    hipLaunchKernelGGL(lstm32w_kernel, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+  if (p.wwide32 && p.form32 > 0 && !p.paired) {   // sixteen-row workgroups for every row of the padded batch
+    if (p.form32 == 2)
+      hipLaunchKernelGGL(lstm32w2_kernel, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    else
+      hipLaunchKernelGGL(lstm32w_kernel, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
     return;
   }
   // Paired workgroups (one per CU) for as many groups as fit ONE resident round, 7-wave workgroups for the rest: a

@@ -171,9 +171,9 @@ class Engine(object):
         _lib.check(self._lib.chiron_engine_profile(self._h, 1 if enable else 0))
 
     def profile_read(self):
-        arr = (_lib.KernelStat * 16)()
+        arr = (_lib.KernelStat * 32)()
         n = C.c_int32()
-        _lib.check(self._lib.chiron_engine_profile_read(self._h, arr, 16, C.byref(n)))
+        _lib.check(self._lib.chiron_engine_profile_read(self._h, arr, 32, C.byref(n)))
         out = {}
         for i in range(n.value):
             s = arr[i]

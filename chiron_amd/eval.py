@@ -469,12 +469,17 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
         finishers = ThreadPoolExecutor(max_workers=n_threads)
     finishing = []
 
-    def drain(slot):
+    def collect(slot):
+        """-> (batch, result) of the slot's finished batch, or None: the slot is free for the next submit afterwards"""
         if inflight[slot] is None:
+            return None
+        batch, inflight[slot] = inflight[slot], None
+        return batch, engine.collect(slot)
+
+    def regroup(done):
+        if done is None:
             return
-        batch = inflight[slot]
-        res = engine.collect(slot)
-        inflight[slot] = None
+        batch, res = done
         for name, flat, seg_len, qs_list, meta in collector.add_batch(batch, res, want_qs):
             if n_procs > 0:
                 fut = finishers.submit(_finish_read_in_process, name, flat, seg_len, qs_list, flag_dict, meta[0], meta[1])
@@ -483,11 +488,13 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
             finishing.append((name, fut))
 
     def launch(batch):
+        # the slot gets its next batch before the host regroups the finished one: the stream never waits for Python
         slot = step[0] % engine.n_slots
         step[0] += 1
-        drain(slot)
+        done = collect(slot)
         engine.submit(slot, batch.x, batch.seq_len, beam_width=FLAGS.beam, want_prob=want_qs)
         inflight[slot] = batch
+        regroup(done)
 
     def load(name):
         """one input file -> [(read name, DataSet, start time, reading time)]"""
@@ -524,7 +531,7 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
         if last is not None:
             launch(last)
         for slot in range(engine.n_slots):
-            drain((step[0] + slot) % engine.n_slots)
+            regroup(collect((step[0] + slot) % engine.n_slots))
         for name, fut in finishing:
             results[name] = fut.result()
     finally:

@@ -396,12 +396,12 @@ def test_wide_recurrence_agrees_with_the_narrow_form_and_is_repack_stable(dna, r
         ln = ln.copy()
         ln[[2, 9, 33, 47]] = [0, 5, L // 2, L - 7]        # 5 samples: 5 frames for DNA, 1 frame for RNA (ratio 5)
         out = {}
-        for form in ("wide", "narrow"):
-            monkeypatch.setenv("CHIRON_LSTM_WIDE", "1" if form == "wide" else "0")
+        for form in ("wide", "wide2", "narrow"):
+            monkeypatch.setenv("CHIRON_LSTM_WIDE", {"wide": "1", "wide2": "2", "narrow": "0"}[form])
             with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
                 sl = ca.seq_len_for_engine(ln, eng.ratio)
                 out[form] = eng.infer(x, sl, want_logits=True).logits.copy()
-                if form == "wide":
+                if form != "narrow":
                     assert np.array_equal(eng.infer(x, sl, want_logits=True).logits, out[form])     # deterministic
                     perm = np.random.RandomState(5).permutation(B)
                     shuffled = eng.infer(x[perm], sl[perm], want_logits=True).logits
@@ -409,14 +409,18 @@ def test_wide_recurrence_agrees_with_the_narrow_form_and_is_repack_stable(dna, r
                     few = [47, 2, 33, 0, 9]
                     assert np.array_equal(eng.infer(x[few], sl[few], want_logits=True).logits, out[form][few])
                     assert np.array_equal(eng.infer(x[33:34], sl[33:34], want_logits=True).logits, out[form][33:34])
-        monkeypatch.setenv("CHIRON_LSTM_WIDE", "1")
-        with ca.Engine(spec, w, max_batch=23, segment_len=L) as small:
-            assert np.array_equal(small.infer(x[40:63], sl[40:63], want_logits=True).logits, out["wide"][40:63])
+        for form, v in (("wide", "1"), ("wide2", "2")):
+            monkeypatch.setenv("CHIRON_LSTM_WIDE", v)
+            with ca.Engine(spec, w, max_batch=23, segment_len=L) as small:
+                assert np.array_equal(small.infer(x[40:63], sl[40:63], want_logits=True).logits, out[form][40:63])
         monkeypatch.delenv("CHIRON_LSTM_WIDE", raising=False)
-        diff = np.abs(out["wide"] - out["narrow"]).max()
-        assert 0 < diff < 1e-5, diff
         ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
-        assert np.abs(out["wide"] - ref).max() < TOL and np.abs(out["narrow"] - ref).max() < TOL
+        for form in ("wide", "wide2"):
+            diff = np.abs(out[form] - out["narrow"]).max()
+            assert 0 < diff < 1e-5, (form, diff)
+            assert np.abs(out[form] - ref).max() < TOL
+        assert not np.array_equal(out["wide"], out["wide2"])      # tile 24 sums its K-split partial products in another order
+        assert np.abs(out["narrow"] - ref).max() < TOL
 
 
 def test_winograd_conv2b_against_direct_form_and_oracle(dna, rna, monkeypatch):
@@ -462,6 +466,7 @@ def _engine_variants(monkeypatch):
     """(name, dtype, env) of every recurrence / convolution form the regimes are driven through.  The f16 forms are held to
     the fp32 ENGINE (the f16 bound of test_f16_path_tolerance_vs_f32), the fp32 forms to the float64 oracle."""
     return (("fp32", "fp32", {"CHIRON_LSTM_WIDE": "0"}), ("fp32-wide", "fp32", {"CHIRON_LSTM_WIDE": "1"}),
+            ("fp32-wide2", "fp32", {"CHIRON_LSTM_WIDE": "2"}),
             ("fp32-paired", "fp32", {"CHIRON_LSTM_WIDE": "0", "CHIRON_LSTM_PAIR": "1"}),
             ("fp32-split", "fp32-split", {}),
             ("fp16-fused", "fp16", {"CHIRON_LSTM16_FUSED_MIN": "1"}), ("fp16-unfused", "fp16", {"CHIRON_LSTM16_UNFUSED": "1"}),
@@ -1210,10 +1215,21 @@ def test_sharded_call_equals_single_process(tmp_path):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import shard_run
-    rep = shard_run.run(str(tmp_path), n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100)
+    rep = shard_run.run(str(tmp_path / "a"), n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100, keep=True)
     assert rep["identical"] and rep["files_compared"] == 18 and rep["consensus_bases"] > 0
-    merged = open(os.path.join(str(tmp_path), "out_2ranks", "merged.fastq")).read().split("\n")
+    merged = open(os.path.join(str(tmp_path / "a"), "chunk_000000", "out_2ranks", "merged.fastq")).read().split("\n")
     assert [l for l in merged[0::4] if l] == ["@read%05d" % i for i in range(9)]
+    # fast5 input (the direct path: one partition decides which rank decodes AND basecalls a file), in chunks that are deleted
+    # as they finish; a second call with the same workdir resumes from state.json and repeats nothing
+    import time
+    wd = str(tmp_path / "b")
+    rep5 = shard_run.run(wd, n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100, chunk=5, kind="fast5")
+    assert rep5["identical"] and rep5["chunks"] == 2 and rep5["files_compared"] == 18
+    assert rep5["consensus_bases"] == rep["consensus_bases"] and rep5["merged_bytes"] == rep["merged_bytes"]     # same reads, same calls
+    assert sorted(os.listdir(wd)) == ["model", "state.json"]                                            # nothing else left on disk
+    t0 = time.time()
+    again = shard_run.run(wd, n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100, chunk=5, kind="fast5")
+    assert again == rep5 and time.time() - t0 < 2.0
 
 
 def test_device_consensus_equals_host_vote(tmp_path):

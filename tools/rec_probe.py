@@ -25,7 +25,7 @@ def probe(B, L=400, jump=390, reps=5):
             eng.infer(x[:B], sl)
         st = eng.profile_read()
         eng.profile(False)
-    return {k: round(v["total_ms"] / v["launches"], 4) for k, v in st.items() if k in ("lstm_recurrence", "lstm_proj_dma", "conv_wino")}
+    return {k: round(v["total_ms"] / v["launches"], 4) for k, v in st.items() if k in ("lstm_recurrence", "lstm_proj_dma", "lstm_proj0_dma", "conv_wino", "conv2a", "conv_dma", "conv_res")}
 
 
 if __name__ == "__main__":
