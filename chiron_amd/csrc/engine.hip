@@ -842,7 +842,9 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   // fp32 recurrence form: CHIRON_LSTM_WIDE=1 -> lstm32w_kernel (16 rows per workgroup), =0 -> lstm_kernel (4 rows); read once here
   {
     const char* wv = getenv("CHIRON_LSTM_WIDE");
-    e->lstm_form = wv ? atoi(wv) : CHIRON_LSTM_WIDE_DEFAULT;
+    // (fp32-split: the GEMMs take a third of their fp32 time, the recurrence dominates and nothing fills the CUs a wide
+    // launch leaves alone -- the 4-row form, 1.10 against 1.29 ms per launch, is the faster one there)
+    e->lstm_form = wv ? atoi(wv) : (e->split ? 0 : CHIRON_LSTM_WIDE_DEFAULT);
     if (e->lstm_form < 0 || e->lstm_form > 2) e->lstm_form = CHIRON_LSTM_WIDE_DEFAULT;
   }
   e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;

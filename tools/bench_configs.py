@@ -20,7 +20,7 @@ def run(name, spec, L, jump, B, beam, steps=20, dtype="fp32"):
     sig = ca.synthetic_signal(1, jump * (B - 1) + L, seed=5)[0]
     x, ln = signal_io.window_signal(sig, 0, jump, L)
     x, ln = x[:B], ln[:B]
-    NS = int(os.environ.get("BENCH_SLOTS", "2"))
+    NS = int(os.environ.get("BENCH_SLOTS", "3"))      # what `chiron call` and bench.py keep in flight
     with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=NS, max_beam=beam, dtype=dtype) as eng:
         sl = ca.seq_len_for_engine(ln, eng.ratio)
         for _ in range(2):
@@ -31,10 +31,11 @@ def run(name, spec, L, jump, B, beam, steps=20, dtype="fp32"):
         nb = 0
         for i in range(steps):
             s = i % NS
-            if pend[s]:
-                nb += eng.collect(s).decoded.values.shape[0]
-            eng.submit(s, x, sl, beam_width=beam, want_prob=True)
+            res = eng.collect(s) if pend[s] else None
+            eng.submit(s, x, sl, beam_width=beam, want_prob=True)     # the slot gets its next batch before the host looks at the last
             pend[s] = True
+            if res is not None:
+                nb += res.decoded.values.shape[0]
         for s in range(NS):
             if pend[s]:
                 nb += eng.collect(s).decoded.values.shape[0]

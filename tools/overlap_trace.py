@@ -14,7 +14,7 @@ def main():
     rows = []
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], r.get("Queue_Id", "")))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], r.get("Queue_Id", "")))
     rows.sort()
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     lo = t0 + int((t1 - t0) * skip)

@@ -23,6 +23,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o slots1 --
 cp "$OUT"/prof/slots1_kernel_stats.csv "$OUT/${R}_kernel_stats_slots1.csv" 2>/dev/null || \
   find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_kernel_stats_slots1.csv" \;
 
+# 2b. the same command with THREE batches in flight (the regime the headline is quoted in): kernel trace -> how many kernels are
+#     resident over time, per-kernel durations in the mix (tools/overlap_trace.py)
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof3" -o slots3 -- \
+  python bench.py --slots 3 --steps 20 --rounds 2 --host-rounds 0 --warmup 3 --no-f16 --no-cpu-baseline > "$OUT/bench_slots3_traced.json" 2> "$OUT/bench_slots3_traced.err"
+python tools/overlap_trace.py "$(find "$OUT/prof3" -name '*kernel_trace.csv' | head -1)" 0.1 > "$OUT/${R}_overlap_slots3.txt" 2>> "$OUT/bench_slots3_traced.err"
+
 # 3. the default bench command, three times
 for i in 1 2 3; do python bench.py > "$OUT/bench_default_$i.json" 2> "$OUT/bench_default_$i.err"; done
 cp "$OUT/bench_default_1.json" "$OUT/bench_default.json"
@@ -41,6 +47,15 @@ python tools/e2e_bench.py 512 30 - fp32 1100 signal >> "$OUT/e2e.txt" 2>> "$OUT/
 python tools/e2e_bench.py 512 30 - fp32 1100 fast5 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
 python tools/e2e_bench.py 2048 0 - fp16 4096 signal >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
 python tools/e2e_bench.py 2048 0 - fp16 4096 fast5 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+
+# 5b. the beam-search kernel on its own: engine logits (flat posteriors) and trained-model-like peaked posteriors, kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/beam" -o beam -- python tools/beam_peaked.py 1100 > "$OUT/${R}_beam_kernel.txt" 2> "$OUT/beam.err"
+python - "$OUT" >> "$OUT/${R}_beam_kernel.txt" <<'PY'
+import csv, glob, os, sys
+f = glob.glob(os.path.join(sys.argv[1], "beam/**/*kernel_stats.csv"), recursive=True)
+for row in list(csv.DictReader(open(f[0])))[:8]:
+    print("%-70s calls %4s avg %9.1f us  %5s %%" % (row["Name"][:70], row["Calls"], float(row["AverageNs"]) / 1e3, row["Percentage"]))
+PY
 
 # 6. fp16 engine at configs[4], kernel trace
 bash tools/f16_profile.sh > "$OUT/f16_kernels.txt" 2> "$OUT/f16_kernels.err"
