@@ -30,6 +30,9 @@ namespace chiron {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// a * b + c on two fp32 values at once (v_pk_fma_f32)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 typedef void __attribute__((address_space(3)))* lptr_t;
 
 namespace {
@@ -428,23 +431,36 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
       const float* brow = t0 + 4 * P_F + (wn * 32 + li) * K4;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const f32x4 d0 = first ? *reinterpret_cast<const f32x4*>(zrow) : *reinterpret_cast<const f32x4*>(p3 + fs0[g]);
+        // the two padded inputs are chosen by ADDRESS (one select each), not by value (four each)
+        const float* a0 = first ? zrow : p3 + fs0[g];
+        const float* a5 = last ? zrow : p0 + K4 + fs1[g];
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(a0);
         const f32x4 d1 = *reinterpret_cast<const f32x4*>(p0 + fs0[g]);
         const f32x4 d2 = *reinterpret_cast<const f32x4*>(p1 + fs0[g]);
         const f32x4 d3 = *reinterpret_cast<const f32x4*>(p2 + fs0[g]);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(p3 + K4 + fs1[g]);
-        const f32x4 d5 = last ? *reinterpret_cast<const f32x4*>(zrow) : *reinterpret_cast<const f32x4*>(p0 + K4 + fs1[g]);
+        const f32x4 d5 = *reinterpret_cast<const f32x4*>(a5);
         f32x4 u[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) u[j] = *reinterpret_cast<const f32x4*>(brow + j * U4_F + fs0[g]);
-        const f32x4 a = d4 - 4.0f * d2, b = d3 - 4.0f * d1, cc = d4 - d2, e = d3 - d1;
+        // input transform v = B^T d on PACKED fp32 (v_pk_fma_f32 / v_pk_add_f32: two values per instruction; every VALU
+        // instruction of this loop is paid in matrix-pipe time): 12 packed operations per pair instead of 24 scalar ones
         f32x4 v[6];
-        v[0] = 4.0f * d0 + (d4 - 5.0f * d2);
-        v[1] = a + b;
-        v[2] = a - b;
-        v[3] = cc + 2.0f * e;
-        v[4] = cc - 2.0f * e;
-        v[5] = 4.0f * d1 + (d5 - 5.0f * d3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 e0 = {d0[2 * h], d0[2 * h + 1]}, e1 = {d1[2 * h], d1[2 * h + 1]}, e2 = {d2[2 * h], d2[2 * h + 1]};
+          const f32x2 e3 = {d3[2 * h], d3[2 * h + 1]}, e4 = {d4[2 * h], d4[2 * h + 1]}, e5 = {d5[2 * h], d5[2 * h + 1]};
+          const f32x2 c4 = {4.0f, 4.0f}, c5 = {5.0f, 5.0f}, c2 = {2.0f, 2.0f};
+          const f32x2 a = pk_fma(-c4, e2, e4), b = pk_fma(-c4, e1, e3), cc = e4 - e2, e = e3 - e1;
+          const f32x2 w0 = pk_fma(c4, e0, pk_fma(-c5, e2, e4)), w1 = a + b, w2 = a - b, w3 = pk_fma(c2, e, cc), w4 = pk_fma(-c2, e, cc),
+                      w5 = pk_fma(c4, e1, pk_fma(-c5, e3, e5));
+          v[0][2 * h] = w0[0], v[0][2 * h + 1] = w0[1];
+          v[1][2 * h] = w1[0], v[1][2 * h + 1] = w1[1];
+          v[2][2 * h] = w2[0], v[2][2 * h + 1] = w2[1];
+          v[3][2 * h] = w3[0], v[3][2 * h + 1] = w3[1];
+          v[4][2 * h] = w4[0], v[4][2 * h + 1] = w4[1];
+          v[5][2 * h] = w5[0], v[5][2 * h + 1] = w5[1];
+        }
         if (go) issue_part(g, nc, nxt);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
