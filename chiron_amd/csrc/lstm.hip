@@ -783,6 +783,19 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
           for (int g = 0; g < NG; ++g) acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha[g], wh[n][ks], acc[g][n], 0, 0, 0);
         }
     }
+    // next step's x pieces go to the LDS HERE, behind the products and before this step's output stores: vmcnt counts loads
+    // and stores together, so waiting for the pieces after the stores (round 2) made every step wait for its own stores'
+    // write acknowledgements; now the stores have a whole step to drain.  (xbuf[cur ^ 1] was last read in step s - 1.)
+    if (NG == 2)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre[0]), "+v"(xpre[NG - 1]) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre[0]) : : "memory");
+    if (xlive && s + 1 < maxlen) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        *reinterpret_cast<f32x4*>(xbuf + ((cur ^ 1) * NG + g) * XQ * 128 + xw0) = xpre[g];
+      }
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -805,16 +818,6 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
           hbuf[((cur ^ 1) * NG + g) * HF16 + h_pos(n)] = act ? (_Float16)hnew : hold;
           outh[to * ostep + olane + g * 16 * outw + 4 * n] = (_Float16)(act ? hnew : 0.f);
         }
-      }
-    }
-    if (NG == 2)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre[0]), "+v"(xpre[NG - 1]) : : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre[0]) : : "memory");
-    if (xlive && s + 1 < maxlen) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        *reinterpret_cast<f32x4*>(xbuf + ((cur ^ 1) * NG + g) * XQ * 128 + xw0) = xpre[g];
       }
     }
     cur ^= 1;

@@ -57,6 +57,9 @@ for row in list(csv.DictReader(open(f[0])))[:8]:
     print("%-70s calls %4s avg %9.1f us  %5s %%" % (row["Name"][:70], row["Calls"], float(row["AverageNs"]) / 1e3, row["Percentage"]))
 PY
 
+echo "--- PMC of beam64_kernel (16 launches: beam 30 / 50 on peaked and flat posteriors; per-launch means)" >> "$OUT/${R}_beam_kernel.txt"
+bash tools/pmc_beam.sh "$OUT/pmc_beam" >> "$OUT/${R}_beam_kernel.txt" 2>> "$OUT/beam.err"
+
 # 6. fp16 engine at configs[4], kernel trace
 bash tools/f16_profile.sh > "$OUT/f16_kernels.txt" 2> "$OUT/f16_kernels.err"
 
