@@ -34,8 +34,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef void __attribute__((address_space(3)))* lptr_t;
 
-namespace {
-
 constexpr unsigned T_OOB = 0xFFFF0000u;      // byte offset past num_records: the DMA writes zeros
 constexpr unsigned T_RECORDS = 0xFFFE0000u;  // every tensor of the engine is smaller than this many bytes
 constexpr int T_ROWS = 32;                   // positions per tile
@@ -46,13 +44,13 @@ constexpr int T_NW = 8;                      // waves per workgroup
 
 // s_barrier between producer and consumer waves (see stream16.hip): compiler-only fences around the hardware barrier; no
 // s_waitcnt vmcnt, which would make every compute wave wait for its own output stores once per tile.
-__device__ __forceinline__ void tile_barrier() {
+static __device__ __forceinline__ void tile_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t t_rsrc(const void* base) {
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t t_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, T_RECORDS, 0x00027000);
 }
 
@@ -150,8 +148,6 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
     }
   }
 }
-
-}  // namespace
 
 bool launch_stream32(const GemmParams& p, hipStream_t stream) {
   // 256 -> 256 channel 1 x 1 convolution, fp32, channels-last in and out, no K tail

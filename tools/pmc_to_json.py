@@ -16,7 +16,7 @@ def family(name):
     if "gemm_f32_dma_kernel" in n or "gemm_f32_kernel" in n:
         return n.replace("void ", "").replace("chiron::", "").strip()
     if "lstm_kernel<" in n or "lstm32w" in n or "conv1x1_f32_stream_kernel" in n:
-        return n.replace("void ", "").replace("chiron::", "").replace("(anonymous namespace)::", "").strip()
+        return n.replace("void ", "").replace("chiron::", "").strip()
     if "wino_conv3" in n:
         return n.replace("void ", "").replace("chiron::", "").strip()
     for key in ("pwl_conv_kernel", "lstm16_kernel", "lstm_kernel", "fc_kernel", "beam64_kernel", "greedy_kernel", "beam_kernel", "scan_kernel", "scatter_kernel"):
