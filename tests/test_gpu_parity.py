@@ -129,6 +129,32 @@ def test_errors_through_the_abi(dna):
         with pytest.raises(_lib.ChironError) as ei:
             eng.infer(np.zeros((2, 400), np.float32), np.zeros(2, np.int32), beam_width=5)   # max_beam=0 at create
         assert ei.value.status == _lib.ERR_OVERFLOW
+        # chiron_engine_features (getcnnfeature): nothing to return before the first batch, not while a batch is in flight;
+        # a submit that is refused (slot busy) leaves the batch in flight and its keep-alive untouched
+        with pytest.raises(_lib.ChironError) as ei:
+            eng.features()
+        assert ei.value.status == _lib.ERR_STATE
+        xs, ls = _windows(390 * 3 + 100, 400, 390, seed=3)
+        eng.submit(0, xs, ca.seq_len_for_engine(ls, eng.ratio))
+        kept = eng._keep[0]
+        with pytest.raises(_lib.ChironError) as ei:
+            eng.features()
+        assert ei.value.status == _lib.ERR_STATE
+        with pytest.raises(_lib.ChironError) as ei:
+            eng.submit(0, xs[:2], ca.seq_len_for_engine(ls[:2], eng.ratio))
+        assert ei.value.status == _lib.ERR_STATE and eng._keep[0] is kept
+        eng.collect(0)
+        fea = eng.features()
+        assert fea.shape == (xs.shape[0], eng.T, 256) and np.isfinite(fea).all() and fea.min() >= 0.0    # the last block ends in a ReLU
+    with ca.Engine(spec, w, max_batch=8, segment_len=400, dtype="fp16") as e16:
+        e16.infer(xs, ca.seq_len_for_engine(ls, e16.ratio))
+        f16 = e16.features()                       # halves, widened
+        assert f16.shape == fea.shape and np.abs(f16 - fea).max() < 0.05 * max(1.0, float(np.abs(fea).max()))
+    with ca.Engine(spec, w, max_batch=8, segment_len=400, dtype="fp32-split") as es:
+        es.infer(xs, ca.seq_len_for_engine(ls, es.ratio))
+        with pytest.raises(_lib.ChironError) as ei:
+            es.features()
+        assert ei.value.status == _lib.ERR_INVALID
 
 
 def test_full_batch_1100_properties(dna):
