@@ -649,6 +649,20 @@ __global__ __launch_bounds__(64 * W16_NW, 2) void lstm16w_kernel(const LstmParam
 // ---------------------------------------------------------------------------------------------------------
 constexpr int F16_KS = 4;        // fused kernel: k-steps of 32 over the hidden state (K = 100 padded to 128)
 constexpr int HF16 = 16 * 128;   // halves per h buffer of the fused kernel: [16 k octets][16 rows][8 halves]
+// The x tiles of lstm16f_kernel live in DYNAMIC shared memory: with a static array the compiler proves that the LDS-DMA of a
+// step and the tile reads of the same step touch one object and puts an s_waitcnt vmcnt(0) between them -- every step would wait
+// for the prefetch it has just issued.  The dynamic region starts where the static one ends; its address is taken from
+// __builtin_amdgcn_groupstaticsize() (an `extern __shared__` array anywhere near the template makes hipcc 7.2 drop the kernel's
+// host stub: "Declaration may not be in a Comdat").
+static __device__ __forceinline__ _Float16* lstm16f_xtiles() {
+  const unsigned base = (__builtin_amdgcn_groupstaticsize() + 15u) & ~15u;
+  return (_Float16*)(__attribute__((address_space(3))) _Float16*)(unsigned long)base;
+}
+// The LDS-DMA goes through this plain function: the builtin written inside the template kernel makes hipcc 7.2 drop the
+// kernel's host stub as well (same diagnostic).
+static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, _Float16* dst, unsigned off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+}
 template <int KSX, int NG>
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParams p) {
   // NG = 2: one workgroup carries TWO 16-row groups through the same weight registers (every weight fragment feeds two
@@ -657,7 +671,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
   constexpr int XQ = KSX * 4;                       // k octets (8 halves) of the x tile: KSX k-steps of 32
   constexpr int NTR = NG == 2 ? 3 : 4;              // column-tile slots whose W_x lives in registers (NG = 2: wave 7's fourth in LDS)
   __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * NG * HF16];
-  __shared__ __attribute__((aligned(16))) _Float16 xbuf[2 * NG * XQ * 128];
+  _Float16* const xbuf = lstm16f_xtiles();   // [3][NG][XQ octets][16 rows][8 halves]: three deep, the pieces of step s + 2 fly while s is consumed
   __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * NG * W16_XF];
   __shared__ __attribute__((aligned(16))) _Float16 wx3[NG == 2 ? KSX * 64 * 8 : 8];   // wave 7, tile slot 3: W_x fragments
 
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     }
   }
   for (int i = tid; i < 2 * NG * HF16; i += 64 * W16_NW) hbuf[i] = (_Float16)0.f;
-  for (int i = tid; i < 2 * NG * XQ * 128; i += 64 * W16_NW) xbuf[i] = (_Float16)0.f;
+  for (int i = tid; i < 3 * NG * XQ * 128; i += 64 * W16_NW) xbuf[i] = (_Float16)0.f;
 
   const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;
   const int row = 4 * q + gp;
@@ -701,29 +715,47 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
 #pragma unroll
   for (int n = 0; n < W16_NT; ++n) bias[n] = n < nt ? p.xbias[dir * 4 * p.H + gp * p.H + 4 * (tile0 + n) + u] : 0.f;
 
-  // ---- x loader: this thread's piece (16 bytes: k = 8 xj .. 8 xj + 7 of row xr) of each group's tile
-  const int xr = tid >> 5, xj = tid & 31;
-  const bool xlive = 8 * xj < p.xK;
-  const char* const xsrc = reinterpret_cast<const char*>(p.xsrc);
+  // ---- x loader (round 3): LDS-DMA, TWO steps ahead.  One instruction per wave, group and step: wave w fetches octets
+  //      4w .. 4w+3 of all 16 rows (lane -> octet 4w + (lane >> 4), row lane & 15: the tile's [octet][row][8 halves] order is
+  //      lane-linear in exactly that numbering), straight into the buffer of step s + 2 -- no staging registers, no ds_write,
+  //      and a row's piece has two whole steps to arrive (it is gathered from HBM: the backward direction walks
+  //      t = seq_len - 1 - s per row; round 2 fetched one step ahead into registers and stalled on the gather every step).
+  const int xr = lane & 15, xj = 4 * wave + (lane >> 4);
+  const bool xwave = 4 * wave < XQ;                  // K = 200: 28 octets, wave 7 has none
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xsrc), 0, 0xFFFE0000u, 0x00027000);
   int xlen[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) xlen[g] = min(p.seq_len[(g0 + g) * 16 + xr], p.T);
   auto x_offset = [&](int g, int s) -> unsigned {   // byte offset of the piece for step s (any valid frame for a finished row)
-    const int xb = (g0 + g) * 16 + xr;
+    int xro = xr;
+    asm volatile("" : "+v"(xro));   // recomputed every step: hoisted, the per-group row bases are spilled (256 VGPRs) and every
+                                    // reload brings an s_waitcnt vmcnt(0) -- a wait for the prefetch just issued
+    const int xb = (g0 + g) * 16 + xro;
     int t = dir == 0 ? s : xlen[g] - 1 - s;
     t = min(max(t, 0), p.T - 1);
     // rows past the submitted batch have length 0 and are never consumed; they read row B - 1 (the feature tensor holds B rows)
     const unsigned r = p.x_time_major ? (unsigned)t * p.BP + xb : (unsigned)min(xb, p.B - 1) * p.T + t;
-    return (r * p.xld + (xlive ? 8 * xj : 0)) * 2u;
+    return 8 * xj < p.xK ? (r * p.xld + 8 * xj) * 2u : 0xFFFF0000u;   // octets past K read zeros (offset past num_records)
   };
-  const int xw0 = (xj * 16 + xr) * 8;                // halves: octet j of the row, [octet][row][8]
-  __syncthreads();   // the zero fill above is complete before the first pieces land
-  if (xlive && maxlen > 0) {
+  auto x_issue = [&](int s, int buf) {
+    if (!xwave) return;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      *reinterpret_cast<f32x4*>(xbuf + g * XQ * 128 + xw0) = *reinterpret_cast<const f32x4*>(xsrc + x_offset(g, 0));
-    }
+    for (int g = 0; g < NG; ++g)
+      lds_dma16(xrs, xbuf + ((buf * NG + g) * XQ + 4 * wave) * 128, x_offset(g, s));
+  };
+  // barrier of this kernel's loop: LDS writes of the step (h, scratch) complete, then s_barrier -- and NO vmcnt wait (a
+  // __syncthreads() drains vmcnt while an LDS-DMA is pending, which would put the prefetch back to one step)
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  __syncthreads();   // the zero fill above is complete before the first pieces land
+  if (maxlen > 0) {
+    x_issue(0, 0);
+    x_issue(1, 1);
   }
+  // (the builtin, not inline asm: the compiler's own wait-count bookkeeping has to see that nothing is pending at loop entry,
+  //  or it keeps a vmcnt(0) for the pre-loop loads INSIDE the loop, where it would wait for every step's prefetch)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); expcnt / lgkmcnt untouched
   __syncthreads();
 
   const unsigned outw = p.ndir * p.H;
@@ -740,17 +772,9 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
   for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int n = 0; n < W16_NT; ++n) c[g][n] = 0.f;
-  int cur = 0;
+  int cur = 0, xcur = 0;   // h buffer / x buffer of this step
   for (int s = 0; s < maxlen; ++s) {
-    // next step's pieces, in flight during this step's arithmetic.  Issued by every lane on every step (lanes past K and the
-    // last step fetch a valid address and drop the data): the registers must have the asm as their only definition, a merge
-    // with an older value would let the compiler copy them before the load has landed.
-    f32x4 xpre[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const char* src = xsrc + x_offset(g, s + 1);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xpre[g]) : "v"(src) : "memory");
-    }
+    x_issue(s + 2, xcur == 0 ? 2 : xcur - 1);   // into the buffer consumed in step s - 1 (every wave is past that step's barrier)
     f32x4 acc[NG][W16_NT];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -760,7 +784,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     for (int ks = 0; ks < KSX; ++ks) {
       f16x8 xa[NG];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) xa[g] = reinterpret_cast<const f16x8*>(xbuf + (cur * NG + g) * XQ * 128)[ks * 64 + lane];
+      for (int g = 0; g < NG; ++g) xa[g] = reinterpret_cast<const f16x8*>(xbuf + (xcur * NG + g) * XQ * 128)[ks * 64 + lane];
 #pragma unroll
       for (int n = 0; n < W16_NT; ++n)
         if (n < nt) {
@@ -783,19 +807,12 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
           for (int g = 0; g < NG; ++g) acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha[g], wh[n][ks], acc[g][n], 0, 0, 0);
         }
     }
-    // next step's x pieces go to the LDS HERE, behind the products and before this step's output stores: vmcnt counts loads
-    // and stores together, so waiting for the pieces after the stores (round 2) made every step wait for its own stores'
-    // write acknowledgements; now the stores have a whole step to drain.  (xbuf[cur ^ 1] was last read in step s - 1.)
-    if (NG == 2)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre[0]), "+v"(xpre[NG - 1]) : : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xpre[0]) : : "memory");
-    if (xlive && s + 1 < maxlen) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        *reinterpret_cast<f32x4*>(xbuf + ((cur ^ 1) * NG + g) * XQ * 128 + xw0) = xpre[g];
-      }
-    }
+    // the pieces of step s + 1 (issued during step s - 1) have landed when at most this step's NG instructions are
+    // outstanding.  The wait sits HERE, behind the products and before this step's output stores: vmcnt counts loads and stores
+    // together, and behind the stores (round 2) it made every step wait for its own stores' write acknowledgements.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(NG == 2 ? 0x0F72 : 0x0F71);   // vmcnt(NG)
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -821,8 +838,10 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
       }
     }
     cur ^= 1;
-    __syncthreads();
+    xcur = xcur == 2 ? 0 : xcur + 1;
+    step_barrier();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last two prefetches (never consumed) before the workgroup may retire
 
   for (int s = maxlen; s < p.T; ++s)
     for (int i = tid; i < 16 * NG * p.H; i += 64 * W16_NW) {
@@ -1155,14 +1174,14 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
     const int g16 = p.BP / 16;
     if (g16 % 2 == 0 && p.fused_pair) {
       if (p.xK > 224)
-        hipLaunchKernelGGL((lstm16f_kernel<8, 2>), dim3((g16 / 2) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+        hipLaunchKernelGGL((lstm16f_kernel<8, 2>), dim3((g16 / 2) * p.ndir), dim3(64 * W16_NW), 3 * 2 * 32 * 128 * 2 + 16, stream, p);
       else
-        hipLaunchKernelGGL((lstm16f_kernel<7, 2>), dim3((g16 / 2) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+        hipLaunchKernelGGL((lstm16f_kernel<7, 2>), dim3((g16 / 2) * p.ndir), dim3(64 * W16_NW), 3 * 2 * 28 * 128 * 2 + 16, stream, p);
     } else {
       if (p.xK > 224)
-        hipLaunchKernelGGL((lstm16f_kernel<8, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+        hipLaunchKernelGGL((lstm16f_kernel<8, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 3 * 32 * 128 * 2 + 16, stream, p);
       else
-        hipLaunchKernelGGL((lstm16f_kernel<7, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+        hipLaunchKernelGGL((lstm16f_kernel<7, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 3 * 28 * 128 * 2 + 16, stream, p);
     }
     return;
   }
