@@ -663,6 +663,9 @@ static __device__ __forceinline__ _Float16* lstm16f_xtiles() {
 static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, _Float16* dst, unsigned off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
 }
+#ifndef CHIRON_F16F_VARIANT
+#define CHIRON_F16F_VARIANT 0   // timing experiments only (tools/variants.sh): 1 no gate math, 2 no MFMAs, 4 no output stores, 5 no x prefetch
+#endif
 template <int KSX, int NG>
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParams p) {
   // NG = 2: one workgroup carries TWO 16-row groups through the same weight registers (every weight fragment feeds two
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
   constexpr int NTR = NG == 2 ? 3 : 4;              // column-tile slots whose W_x lives in registers (NG = 2: wave 7's fourth in LDS)
   __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * NG * HF16];
   _Float16* const xbuf = lstm16f_xtiles();   // [3][NG][XQ octets][16 rows][8 halves]: three deep, the pieces of step s + 2 fly while s is consumed
-  __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * NG * W16_XF];
+  __shared__ __attribute__((aligned(16))) f32x4 biasq[W16_NW * W16_NT * 4];             // [wave][tile slot][unit of the tile] -> (i, j, f, o)
   __shared__ __attribute__((aligned(16))) _Float16 wx3[NG == 2 ? KSX * 64 * 8 : 8];   // wave 7, tile slot 3: W_x fragments
 
   const int tid = threadIdx.x;
@@ -703,17 +706,27 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
   for (int i = tid; i < 2 * NG * HF16; i += 64 * W16_NW) hbuf[i] = (_Float16)0.f;
   for (int i = tid; i < 3 * NG * XQ * 128; i += 64 * W16_NW) xbuf[i] = (_Float16)0.f;
 
-  const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;
-  const int row = 4 * q + gp;
+  // The product is computed TRANSPOSED (round 3): the weight fragments are the A operand, the x / h tiles the B operand --
+  // both operands have the same lane layout, so it is a swap of the two arguments -- and D = (x W)^T arrives as lane
+  // (batch row = lane & 15, unit of the tile = lane >> 4) holding rows 4u .. 4u+3 of D^T: the gates i, j, f, o of ONE
+  // cell in the lane's four registers.  No transpose at all (round 2: 1.1 KB of wave-private LDS per tile, one
+  // ds_write_b128 + four ds_read_b32 per tile and step, 0.14 of the 1.48 ms launch at B = 4096).
+  const int row = lane & 15, u = lane >> 4;
   int lenr[NG], maxlen = 0;
 #pragma unroll
   for (int g = 0; g < NG; ++g) lenr[g] = min(p.seq_len[(g0 + g) * 16 + row], p.T);
   for (int r = 0; r < 16 * NG; ++r) maxlen = max(maxlen, min(p.seq_len[g0 * 16 + r], p.T));
 
-  // bias (+ forget bias) of this lane's column of each tile: the C operand the tile's first MFMA starts from
-  float bias[W16_NT];
-#pragma unroll
-  for (int n = 0; n < W16_NT; ++n) bias[n] = n < nt ? p.xbias[dir * 4 * p.H + gp * p.H + 4 * (tile0 + n) + u] : 0.f;
+  // bias (+ forget bias) of a cell's four gates: the C operand the tile's first MFMA starts from, read from the LDS every
+  // step (16 registers per lane otherwise; the kernel sits at 256)
+  if (tid < W16_NW * W16_NT * 4) {
+    const int bw = tid >> 4, bn = (tid >> 2) & 3, bu = tid & 3;
+    const int unit = 4 * (3 * bw + bn) + bu;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (bn < (bw == W16_NW - 1 ? 4 : 3) && unit < p.H)
+      for (int gt = 0; gt < 4; ++gt) b[gt] = p.xbias[dir * 4 * p.H + gt * p.H + unit];
+    biasq[tid] = b;
+  }
 
   // ---- x loader (round 3): LDS-DMA, TWO steps ahead.  One instruction per wave, group and step: wave w fetches octets
   //      4w .. 4w+3 of all 16 rows (lane -> octet 4w + (lane >> 4), row lane & 15: the tile's [octet][row][8 halves] order is
@@ -764,8 +777,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
   // cell (row, unit 4 T + u) of column tile T: octet T / 2, element 4 (T % 2) + u  ->  + 4 per tile, + 120 more every second
   auto h_pos = [&](int n) -> int { const int T = tile0 + n; return ((T >> 1) * 16 + row) * 8 + 4 * (T & 1) + u; };
   _Float16* outh = reinterpret_cast<_Float16*>(p.out);
-  float* const xw = xf + wave * W16_NT * NG * W16_XF + 4 * lane + 4 * q;
-  const float* const xrd = xf + wave * W16_NT * NG * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+  const f32x4* const biasl = biasq + (wave * W16_NT) * 4 + u;
 
   float c[NG][W16_NT];   // (the carried h of a finished row is re-read from the h tile: its only consumer is that tile)
 #pragma unroll
@@ -774,12 +786,14 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     for (int n = 0; n < W16_NT; ++n) c[g][n] = 0.f;
   int cur = 0, xcur = 0;   // h buffer / x buffer of this step
   for (int s = 0; s < maxlen; ++s) {
+#if CHIRON_F16F_VARIANT != 5
     x_issue(s + 2, xcur == 0 ? 2 : xcur - 1);   // into the buffer consumed in step s - 1 (every wave is past that step's barrier)
+#endif
     f32x4 acc[NG][W16_NT];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int n = 0; n < W16_NT; ++n) acc[g][n] = (f32x4){bias[n], bias[n], bias[n], bias[n]};
+      for (int n = 0; n < W16_NT; ++n) acc[g][n] = n < nt ? biasl[4 * n] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KSX; ++ks) {
       f16x8 xa[NG];
@@ -792,7 +806,12 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
           if (n < NTR) wv = wx[n < NTR ? n : 0][ks];
           else wv = reinterpret_cast<const f16x8*>(wx3)[ks * 64 + lane];
 #pragma unroll
-          for (int g = 0; g < NG; ++g) acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[g], wv, acc[g][n], 0, 0, 0);
+          for (int g = 0; g < NG; ++g)
+#if CHIRON_F16F_VARIANT == 2
+            acc[g][n][0] += (float)xa[g][0] * (float)wv[0];
+#else
+            acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xa[g], acc[g][n], 0, 0, 0);
+#endif
         }
     }
 #pragma unroll
@@ -804,7 +823,12 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
       for (int n = 0; n < W16_NT; ++n)
         if (n < nt) {
 #pragma unroll
-          for (int g = 0; g < NG; ++g) acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha[g], wh[n][ks], acc[g][n], 0, 0, 0);
+          for (int g = 0; g < NG; ++g)
+#if CHIRON_F16F_VARIANT == 2
+            acc[g][n][0] += (float)ha[g][0] * (float)wh[n][ks][0];
+#else
+            acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[n][ks], ha[g], acc[g][n], 0, 0, 0);
+#endif
         }
     }
     // the pieces of step s + 1 (issued during step s - 1) have landed when at most this step's NG instructions are
@@ -814,26 +838,26 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     __builtin_amdgcn_s_waitcnt(NG == 2 ? 0x0F72 : 0x0F71);   // vmcnt(NG)
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int n = 0; n < W16_NT; ++n)
-        if (n < nt) *reinterpret_cast<f32x4*>(xw + (g * W16_NT + n) * W16_XF) = acc[g][n];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
     for (int g = 0; g < NG; ++g) {
       const bool act = s < lenr[g];
       const unsigned to = (dir == 0 || !act) ? s : lenr[g] - 1 - s;
 #pragma unroll
       for (int n = 0; n < W16_NT; ++n) {
         if (n < nt) {
-          const float* xs = xrd + (g * W16_NT + n) * W16_XF;
-          const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};
+          const f32x4 gates = acc[g][n];
           float hnew;
+#if CHIRON_F16F_VARIANT == 1
+          const float cn = gates[0] + gates[1] + gates[2] + gates[3] + c[g][n];
+          hnew = 0.5f * cn;
+#else
           const float cn = lstm_cell(gates, c[g][n], &hnew);
+#endif
           c[g][n] = act ? cn : c[g][n];
           const _Float16 hold = hbuf[(cur * NG + g) * HF16 + h_pos(n)];
           hbuf[((cur ^ 1) * NG + g) * HF16 + h_pos(n)] = act ? (_Float16)hnew : hold;
+#if CHIRON_F16F_VARIANT != 4
           outh[to * ostep + olane + g * 16 * outw + 4 * n] = (_Float16)(act ? hnew : 0.f);
+#endif
         }
       }
     }

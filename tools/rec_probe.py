@@ -16,7 +16,7 @@ def probe(B, L=400, jump=390, reps=5):
     w = ca.synthetic_weights(spec, seed=1234)
     sig = ca.synthetic_signal(1, jump * (B - 1) + L, seed=5)[0]
     x, ln = signal_io.window_signal(sig, 0, jump, L)
-    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=1) as eng:
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=1, dtype=os.environ.get("PROBE_DTYPE", "fp32")) as eng:
         sl = ca.seq_len_for_engine(ln[:B], eng.ratio)
         for _ in range(2):
             eng.infer(x[:B], sl)
