@@ -664,7 +664,7 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, _Flo
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
 }
 #ifndef CHIRON_F16F_VARIANT
-#define CHIRON_F16F_VARIANT 0   // timing experiments only (tools/variants.sh): 1 no gate math, 2 no MFMAs, 4 no output stores, 5 no x prefetch
+#define CHIRON_F16F_VARIANT 0   // timing experiments only (tools/variants.sh), bit mask: 1 no gate math, 2 no MFMAs, 4 no output stores, 8 no x prefetch, 16 no x tile reads, 32 no h tile reads, 64 no h tile writes
 #endif
 template <int KSX, int NG>
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParams p) {
@@ -712,9 +712,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
   // cell in the lane's four registers.  No transpose at all (round 2: 1.1 KB of wave-private LDS per tile, one
   // ds_write_b128 + four ds_read_b32 per tile and step, 0.14 of the 1.48 ms launch at B = 4096).
   const int row = lane & 15, u = lane >> 4;
-  int lenr[NG], maxlen = 0;
-#pragma unroll
-  for (int g = 0; g < NG; ++g) lenr[g] = min(p.seq_len[(g0 + g) * 16 + row], p.T);
+  int maxlen = 0;
   for (int r = 0; r < 16 * NG; ++r) maxlen = max(maxlen, min(p.seq_len[g0 * 16 + r], p.T));
 
   // bias (+ forget bias) of a cell's four gates: the C operand the tile's first MFMA starts from, read from the LDS every
@@ -773,21 +771,51 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
 
   const unsigned outw = p.ndir * p.H;
   const unsigned ostep = p.BP * outw;
-  const unsigned olane = (g0 * 16 + row) * outw + dir * p.H + 4 * tile0 + u;   // + 16 outw per group, + 4 per tile
+  _Float16* outh = reinterpret_cast<_Float16*>(p.out);
+  // ---- outputs (round 3): the h tile every wave completed in step s - 1 is the output of that step; it is copied out at the
+  //      top of step s in 8-byte pieces (4 units): 16 rows x 25 pieces x NG groups = 50 NG per wave -- NG store instructions per
+  //      wave and step, each covering whole 200-byte output rows, instead of one 2-byte store per cell (6 .. 8 instructions
+  //      touching 16 rows each).  The cell phase then knows nothing about sequence lengths: a finished row keeps computing
+  //      (rows are independent columns of the product; its state is never read again) and its outputs are written as zeros here.
+  unsigned f_lds[NG], f_out[NG];
+  int f_len[NG];
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    const int P = min(50 * NG * wave + 50 * k + lane, 400 * NG - 1);   // piece of this lane (lanes 50 .. 63 idle)
+    const int fg = P / 400, rem = P - 400 * fg, fr = rem / 25, fq = rem - 25 * fr;
+    f_lds[k] = fg * HF16 + ((fq >> 1) * 16 + fr) * 8 + 4 * (fq & 1);
+    f_out[k] = ((g0 + fg) * 16 + fr) * outw + dir * p.H + 4 * fq;
+    f_len[k] = min(p.seq_len[(g0 + fg) * 16 + fr], p.T);
+  }
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  auto flush = [&](int sp, int buf) {   // the outputs of step sp, h tile `buf`
+    if (lane < 50) {
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const bool act = sp < f_len[k];
+        const unsigned to = (dir == 0 || !act) ? sp : f_len[k] - 1 - sp;
+        u32x2v v = *reinterpret_cast<const u32x2v*>(hbuf + buf * NG * HF16 + f_lds[k]);
+        if (!act) v = (u32x2v){0u, 0u};
+        *reinterpret_cast<u32x2v*>(outh + (to * ostep + f_out[k])) = v;
+      }
+    }
+  };
   // cell (row, unit 4 T + u) of column tile T: octet T / 2, element 4 (T % 2) + u  ->  + 4 per tile, + 120 more every second
   auto h_pos = [&](int n) -> int { const int T = tile0 + n; return ((T >> 1) * 16 + row) * 8 + 4 * (T & 1) + u; };
-  _Float16* outh = reinterpret_cast<_Float16*>(p.out);
   const f32x4* const biasl = biasq + (wave * W16_NT) * 4 + u;
 
-  float c[NG][W16_NT];   // (the carried h of a finished row is re-read from the h tile: its only consumer is that tile)
+  float c[NG][W16_NT];
 #pragma unroll
   for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int n = 0; n < W16_NT; ++n) c[g][n] = 0.f;
   int cur = 0, xcur = 0;   // h buffer / x buffer of this step
   for (int s = 0; s < maxlen; ++s) {
-#if CHIRON_F16F_VARIANT != 5
+#if !(CHIRON_F16F_VARIANT & 8)
     x_issue(s + 2, xcur == 0 ? 2 : xcur - 1);   // into the buffer consumed in step s - 1 (every wave is past that step's barrier)
+#endif
+#if !(CHIRON_F16F_VARIANT & 4)
+    if (s > 0) flush(s - 1, cur);
 #endif
     f32x4 acc[NG][W16_NT];
 #pragma unroll
@@ -798,7 +826,12 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     for (int ks = 0; ks < KSX; ++ks) {
       f16x8 xa[NG];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) xa[g] = reinterpret_cast<const f16x8*>(xbuf + (xcur * NG + g) * XQ * 128)[ks * 64 + lane];
+      for (int g = 0; g < NG; ++g)
+#if CHIRON_F16F_VARIANT & 16
+        xa[g] = wh[0][g];
+#else
+        xa[g] = reinterpret_cast<const f16x8*>(xbuf + (xcur * NG + g) * XQ * 128)[ks * 64 + lane];
+#endif
 #pragma unroll
       for (int n = 0; n < W16_NT; ++n)
         if (n < nt) {
@@ -807,7 +840,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
           else wv = reinterpret_cast<const f16x8*>(wx3)[ks * 64 + lane];
 #pragma unroll
           for (int g = 0; g < NG; ++g)
-#if CHIRON_F16F_VARIANT == 2
+#if CHIRON_F16F_VARIANT & 2
             acc[g][n][0] += (float)xa[g][0] * (float)wv[0];
 #else
             acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xa[g], acc[g][n], 0, 0, 0);
@@ -818,13 +851,18 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     for (int ks = 0; ks < F16_KS; ++ks) {
       f16x8 ha[NG];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) ha[g] = reinterpret_cast<const f16x8*>(hbuf + (cur * NG + g) * HF16)[ks * 64 + lane];
+      for (int g = 0; g < NG; ++g)
+#if CHIRON_F16F_VARIANT & 32
+        ha[g] = wh[1][g];
+#else
+        ha[g] = reinterpret_cast<const f16x8*>(hbuf + (cur * NG + g) * HF16)[ks * 64 + lane];
+#endif
 #pragma unroll
       for (int n = 0; n < W16_NT; ++n)
         if (n < nt) {
 #pragma unroll
           for (int g = 0; g < NG; ++g)
-#if CHIRON_F16F_VARIANT == 2
+#if CHIRON_F16F_VARIANT & 2
             acc[g][n][0] += (float)ha[g][0] * (float)wh[n][ks][0];
 #else
             acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[n][ks], ha[g], acc[g][n], 0, 0, 0);
@@ -835,28 +873,26 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     // outstanding.  The wait sits HERE, behind the products and before this step's output stores: vmcnt counts loads and stores
     // together, and behind the stores (round 2) it made every step wait for its own stores' write acknowledgements.
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(NG == 2 ? 0x0F72 : 0x0F71);   // vmcnt(NG)
+    __builtin_amdgcn_s_waitcnt(NG == 2 ? 0x0F74 : 0x0F72);   // vmcnt(2 NG)
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const bool act = s < lenr[g];
-      const unsigned to = (dir == 0 || !act) ? s : lenr[g] - 1 - s;
 #pragma unroll
       for (int n = 0; n < W16_NT; ++n) {
         if (n < nt) {
           const f32x4 gates = acc[g][n];
           float hnew;
-#if CHIRON_F16F_VARIANT == 1
+#if CHIRON_F16F_VARIANT & 1
           const float cn = gates[0] + gates[1] + gates[2] + gates[3] + c[g][n];
           hnew = 0.5f * cn;
 #else
           const float cn = lstm_cell(gates, c[g][n], &hnew);
 #endif
-          c[g][n] = act ? cn : c[g][n];
-          const _Float16 hold = hbuf[(cur * NG + g) * HF16 + h_pos(n)];
-          hbuf[((cur ^ 1) * NG + g) * HF16 + h_pos(n)] = act ? (_Float16)hnew : hold;
-#if CHIRON_F16F_VARIANT != 4
-          outh[to * ostep + olane + g * 16 * outw + 4 * n] = (_Float16)(act ? hnew : 0.f);
+          c[g][n] = cn;
+#if !(CHIRON_F16F_VARIANT & 64)
+          hbuf[((cur ^ 1) * NG + g) * HF16 + h_pos(n)] = (_Float16)hnew;
+#else
+          c[g][n] += hnew;
 #endif
         }
       }
@@ -865,6 +901,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     xcur = xcur == 2 ? 0 : xcur + 1;
     step_barrier();
   }
+  if (maxlen > 0) flush(maxlen - 1, cur);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last two prefetches (never consumed) before the workgroup may retire
 
   for (int s = maxlen; s < p.T; ++s)

@@ -16,6 +16,7 @@ from chiron_amd import signal_io
 
 
 def run(name, spec, L, jump, B, beam, steps=20, dtype="fp32"):
+    steps = int(os.environ.get("BENCH_STEPS", steps))     # longer timed regions for same-box A/B runs
     w = ca.synthetic_weights(spec, seed=1234)
     sig = ca.synthetic_signal(1, jump * (B - 1) + L, seed=5)[0]
     x, ln = signal_io.window_signal(sig, 0, jump, L)
