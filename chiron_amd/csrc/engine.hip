@@ -223,7 +223,7 @@ struct chiron_engine {
   int maxB = 0, BP = 0;
   bool stream32 = true;           // fp32: 1 x 1 convolutions on the weight-stationary streaming kernel (CHIRON_NO_STREAM32=1: gemm.hip, A/B switch)
   bool stream16 = true;           // f16: 1 x 1 convolutions on the streaming kernel (CHIRON_NO_STREAM16=1: gemm.hip, A/B switch)
-  bool lstm16_pair = false;       // f16 fused recurrence: two 16-row groups per workgroup (A/B switch)
+  int lstm16_pair = -1;           // f16 fused recurrence, two 16-row groups per workgroup: 1 always, 0 never (CHIRON_LSTM16_PAIR), -1 when single groups would not fit one round
   bool lstm16_fused = false;      // f16: x-projection inside the recurrence (whole 16-row groups that fill the CUs)
   bool lstm16_narrow = false;     // A/B switch: f16 recurrence on 4-row workgroups only
   bool lstm_fixed_roles = false;  // A/B switch: light role always on wave 6
@@ -848,7 +848,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     if (e->lstm_form < 0 || e->lstm_form > 2) e->lstm_form = CHIRON_LSTM_WIDE_DEFAULT;
   }
   e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;
-  e->lstm16_pair = getenv("CHIRON_LSTM16_PAIR") != nullptr;
+  e->lstm16_pair = getenv("CHIRON_LSTM16_PAIR") ? atoi(getenv("CHIRON_LSTM16_PAIR")) : -1;
   e->stream16 = getenv("CHIRON_NO_STREAM16") == nullptr;
   e->stream32 = getenv("CHIRON_NO_STREAM32") == nullptr;
   {
@@ -1227,7 +1227,9 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
       r.xsrc = l == 0 ? (const void*)fea : (const void*)prev;
       r.wxwide = lp.wxwide;
       r.whfused = lp.whfused;
-      r.fused_pair = e->lstm16_pair ? 1 : 0;
+      // one 8-wave workgroup per CU either way (registers): 16-row workgroups that need a second round (B = 4096: 512) take 2 x 0.66 ms,
+      // 256 32-row workgroups 1.24 ms in one; below one round the 16-row form finishes in 0.66 (B = 2048)
+      r.fused_pair = e->lstm16_pair >= 0 ? (e->lstm16_pair ? 1 : 0) : ((BP / 16) * 2 > current_device_cus() ? 1 : 0);
       r.xbias = lp.proj[0].shift;
       r.xK = lp.in_w;
       r.xld = l == 0 ? e->C : e->lasth_ld;
