@@ -51,10 +51,36 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t s_rsrc(const void* base
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, S_RECORDS, 0x00027000);
 }
 
+#ifndef CHIRON_S16_VARIANT
+#define CHIRON_S16_VARIANT 0   // timing experiments only (tools/variants.sh), bit mask: 1 no output stores, 2 no input DMA
+#endif
+// Round 3: both sides of the kernel move WHOLE 512-byte rows per instruction.  Round 2 fetched 32 bytes of each of 32 rows per
+// DMA instruction (octet-major tiles) and stored 16 bytes of each of 32 rows per store instruction: instrumented builds at
+// B = 4096 (0.84 GB in, 0.84 GB out): 0.418 ms, without the stores 0.219, without the loads 0.257, without both 0.194 -- the
+// two directions queued behind each other in the L2 request path, neither near the HBM rate.  Now
+//   * input tiles are ROW-major [32 rows][32 octets][8 halves], one DMA instruction = two rows (as in conv3 below); logical
+//     octet o of row r sits at position o ^ (r & 15), applied to the GLOBAL address of the fetching lane (the LDS side of a
+//     DMA is lane-linear), so that the 16 rows of one ds_read_b128 pass fall on 16 different 16-byte bank groups;
+//   * the f16 results of a tile go to a staging tile of the same layout (two of them: tile j is written while the copy of
+//     tile j - 1 is read) and leave one barrier later as 16-byte pieces of whole rows: 2 store instructions per wave and
+//     tile, each two complete rows.
+constexpr int S_STAGE_H = S_ROWS * S_C;   // halves per staging tile (16 KB)
+//   * no producer waves any more (round 3): with ten waves a SIMD may hold three, i.e. 168 registers per wave, and the
+//     two-segment form (128 weight registers) had one 4-register B fragment in flight -- read, wait, multiply, 32 times per
+//     tile -- and spilled.  Eight waves own 256 registers each: every wave issues the DMA of ITS four rows of tile j + D - 1
+//     right after the barrier of tile j, reads the B fragments of a K-segment sixteen deep, and waits for its own rows of
+//     tile j + 1 before the next barrier.  A wave's vmcnt then counts its DMA loads AND its output stores; loads retire in
+//     order among themselves, so "at most (D - 2) x (loads per tile) outstanding" proves the loads of tile j + 1 complete
+//     whatever the stores do (it may also wait for a store that is one or two tiles old).
 template <int NSEG>
-__global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * S_NW, 1) void conv1x1_f16_stream_kernel(const GemmParams p) {
+  // NSEG = 2 (32 KB per tile): four tiles and two whole staging tiles do not fit; there every wave stages its own 32 x 32
+  // block privately (2 KB, same interval, no second buffer) and stores 64-byte row segments -- 16 rows per instruction
+  constexpr bool PRIV = NSEG == 2;
   constexpr int D = NSEG == 1 ? 6 : 4;                 // tiles resident in the LDS; D - 1 in flight behind the one being consumed
-  extern __shared__ __attribute__((aligned(16))) _Float16 tiles[];   // [D][NSEG][32 octets][32 rows][8 halves]
+  constexpr int IPW = 2 * NSEG;                        // DMA instructions per wave and tile (two rows each)
+  extern __shared__ __attribute__((aligned(16))) _Float16 tiles[];   // [D][NSEG][32 rows][32 octets][8 halves], then the staging tile(s)
+  _Float16* const stage = tiles + D * NSEG * S_TILE_H;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,40 +97,31 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kern
   const int mine = first < ntiles ? (ntiles - first + step - 1) / step : 0;   // tiles of this workgroup
   if (mine == 0) return;
 
-  if (wave >= S_NW) {
-    // ---------------- producers: 16 DMA instructions per segment and tile (two octets x 32 rows each), 8 per producer wave
-    const int pw = wave - S_NW;
-    // (an array of __amdgpu_buffer_rsrc_t with a template-dependent bound makes hipcc 7.2 drop the kernel's host stub)
-    __amdgpu_buffer_rsrc_t rs[2];
-    rs[0] = s_rsrc(p.seg[0].src);
-    rs[1] = s_rsrc(p.seg[NSEG - 1].src);
-    auto issue = [&](int j) {   // tile number j of this workgroup (past the last one: zeros, no memory traffic)
-      const int m = (first + j * step) * S_ROWS + li;
-      const bool ok = j < mine && m < p.M;
-      _Float16* base = tiles + (j % D) * NSEG * S_TILE_H;
+  // ---------------- input: wave w fetches rows 4 w .. 4 w + 3 of every tile
+  // (an array of __amdgpu_buffer_rsrc_t with a template-dependent bound makes hipcc 7.2 drop the kernel's host stub)
+  __amdgpu_buffer_rsrc_t rs[2];
+  rs[0] = s_rsrc(p.seg[0].src);
+  rs[1] = s_rsrc(p.seg[NSEG - 1].src);
+  auto issue = [&](int j) {   // tile number j of this workgroup (past the last one: zeros, no memory traffic)
+    const int m0 = (first + j * step) * S_ROWS;
+    _Float16* base = tiles + (j % D) * NSEG * S_TILE_H;
 #pragma unroll
-      for (int sg = 0; sg < NSEG; ++sg) {
-        const unsigned off = ok ? (unsigned)(((long)m * p.seg[sg].lda + p.seg[sg].col0) * 2 + kh * 16) : S_OOB;
+    for (int sg = 0; sg < NSEG; ++sg) {
 #pragma unroll
-        for (int o = 0; o < 16; o += 2)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[sg], (lptr_t)(base + sg * S_TILE_H + (pw * 16 + o) * S_ROWS * 8), 16,
-                                                   off + (unsigned)(pw * 16 + o) * 16u, 0, 0, 0);   // (the producer has VALU to spare)
+      for (int i = 0; i < 2; ++i) {
+        const int r = 2 * (wave * 2 + i) + kh;               // row of the tile this lane fetches a piece of
+#if CHIRON_S16_VARIANT & 2
+        const bool ok = false;
+#else
+        const bool ok = j < mine && m0 + r < p.M;
+#endif
+        const unsigned off = ok ? (unsigned)(((long)(m0 + r) * p.seg[sg].lda + p.seg[sg].col0) * 2 + ((li ^ (r & 15)) * 16)) : S_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[sg], (lptr_t)(base + sg * S_TILE_H + (wave * 2 + i) * 2 * S_C), 16, off, 0, 0, 0);
       }
-    };
-#pragma unroll
-    for (int j = 0; j < D - 1; ++j) issue(j);
-    for (int j = 0; j < mine; ++j) {
-      // everything but the D - 2 youngest tiles has landed: tile j is complete
-      constexpr int PENDING = (D - 2) * 8 * NSEG;   // this wave's DMA instructions of the D - 2 youngest tiles (<= 63)
-      static_assert(PENDING <= 63, "vmcnt is six bits");
-      __builtin_amdgcn_s_waitcnt(0x0F70 | (PENDING & 15) | ((PENDING >> 4) << 14));   // vmcnt(PENDING); expcnt / lgkmcnt untouched
-      tile_barrier();                      // consumers may read tile j; they have finished tile j - 1
-      issue(j + D - 1);                    // ... whose buffer is the one tile j + D - 1 goes to
     }
-    return;
-  }
+  };
 
-  // ---------------- consumers: wave w owns output columns 32 w .. 32 w + 31
+  // ---------------- weights: wave w owns output columns 32 w .. 32 w + 31
   f16x8 wr[NSEG][16];
   {
     const _Float16* wt = reinterpret_cast<const _Float16*>(p.Wt) + (long)(32 * wave + li) * p.K + 8 * kh;
@@ -113,48 +130,110 @@ __global__ __launch_bounds__(64 * (S_NW + S_NP), 1) void conv1x1_f16_stream_kern
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) wr[sg][ks] = *reinterpret_cast<const f16x8*>(wt + sg * S_C + 16 * ks);
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the weights are in: from here on vmcnt holds tile rows and output stores only
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j) issue(j);
+
   // D[i = column][j = row]: lane (row li), registers r -> column 32 w + 8 (r / 4) + 4 kh + r % 4
   const float* const bias = shl + 32 * wave + 4 * kh;   // + 8 q: the four columns of register group q
   const float* const resa = rsl + 32 * wave + 4 * kh;
   const bool res = p.res_a != nullptr;                  // + sig[b][t * res_stride] * res_a[column] (gemm.hip gemm_epilogue_lean<RES>)
-  _Float16* const outp = reinterpret_cast<_Float16*>(p.out) + 32 * wave + 4 * kh;
   const bool relu = p.relu != 0;
-
+  // B operand of k-step ks: logical octet 2 ks + kh of row li, at position (2 ks + kh) ^ (li & 15): one XOR of the lane's base
+  const unsigned rd0 = (unsigned)li * (S_C * 2) + ((((unsigned)li & 14u) << 4) | (((unsigned)kh ^ ((unsigned)li & 1u)) << 4));   // bytes
+  // staging write: 8 bytes (columns 32 w + 8 q + 4 kh ..) = half kh of piece 4 w + q of row li
+  const unsigned wr0 = (unsigned)li * (S_C * 2) + (unsigned)kh * 8u;
+  // copy-out: store i of this wave = rows 4 w + 2 i + kh, piece li
+  auto copy_out = [&](int jt, f16x8* v) {   // reads the staging tile of tile jt (issued early, consumed by store_out)
+    const char* sb = reinterpret_cast<const char*>(stage + (jt & 1) * S_STAGE_H);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned r = 4 * wave + 2 * i + kh;
+      v[i] = *reinterpret_cast<const f16x8*>(sb + r * (S_C * 2) + (((unsigned)li ^ (r & 15u)) << 4));
+    }
+  };
+  auto store_out = [&](int jt, const f16x8* v) {
+    const int m0 = (first + jt * step) * S_ROWS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + 4 * wave + 2 * i + kh;
+#if CHIRON_S16_VARIANT & 1
+      if (v[i][0] == (_Float16)123.25f)
+#endif
+      if (m < p.M) *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(p.out) + (long)m * p.ldo + 8 * li) = v[i];
+    }
+  };
+  // The barrier of a tile: this wave's rows of the tile have landed (vmcnt, see above), its LDS writes to the staging tile are
+  // complete (lgkmcnt), then s_barrier.  The compiler does not know that the DMA engine writes the tiles: tile_barrier()'s
+  // fences keep every LDS read of a tile behind the barrier that publishes it.
+  auto stage_barrier = [&]() {
+    constexpr int PENDING = (D - 2) * IPW;
+    __builtin_amdgcn_s_waitcnt(0x0070 | (PENDING & 15) | ((PENDING >> 4) << 14));   // vmcnt(PENDING) lgkmcnt(0)
+    tile_barrier();
+  };
   for (int j = 0; j < mine; ++j) {
-    tile_barrier();                        // tile j has landed
-    const _Float16* base = tiles + (j % D) * NSEG * S_TILE_H + (kh * S_ROWS + li) * 8;
+    stage_barrier();                       // tile j has landed; every wave has finished tile j - 1 (and staged its columns)
+    issue(j + D - 1);                      // into the buffer of tile j - 1
+    f16x8 ov[2];
+    if (!PRIV && j > 0) copy_out(j - 1, ov);
+    const char* base = reinterpret_cast<const char*>(tiles + (j % D) * NSEG * S_TILE_H);
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int sg = 0; sg < NSEG; ++sg)
+    for (int sg = 0; sg < NSEG; ++sg) {
+      f16x8 xb[16];   // the whole K-segment of this lane's row: sixteen reads in flight, the products follow as they arrive
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const f16x8 xb = *reinterpret_cast<const f16x8*>(base + sg * S_TILE_H + ks * 2 * S_ROWS * 8);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[sg][ks], xb, acc, 0, 0, 0);
-      }
+      for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const f16x8*>(base + sg * (S_TILE_H * 2) + (rd0 ^ (unsigned)(ks * 32)));
+#ifndef CHIRON_S16_NOFENCE
+      asm volatile("" ::: "memory");   // all sixteen reads are issued before the first product waits for one (the scheduler pairs them up otherwise)
+#endif
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[sg][ks], xb[ks], acc, 0, 0, 0);
+    }
+    if (!PRIV && j > 0) store_out(j - 1, ov);
     const int m = (first + j * step) * S_ROWS + li;
-    if (m < p.M) {
-      _Float16* o = outp + (long)m * p.ldo;
-      float sv = 0.f;
-      if (res) {
-        const int b = m / p.T_out, t = m - b * p.T_out;
-        sv = p.sig[(long)b * p.L + (long)t * p.res_stride];
+    float sv = 0.f;
+    if (res && m < p.M) {
+      const int b = m / p.T_out, t = m - b * p.T_out;
+      sv = p.sig[(long)b * p.L + (long)t * p.res_stride];
+    }
+    char* sw = reinterpret_cast<char*>(stage + (j & 1) * S_STAGE_H) + wr0;
+    char* const pbase = reinterpret_cast<char*>(stage) + wave * 2048;      // PRIV: [32 rows][4 pieces of 16 bytes], piece q of row r at q ^ (r / 4 % 4)
+    char* const pw0 = pbase + (unsigned)li * 64u + (unsigned)kh * 8u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f16x4 hv;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
+      const f32x4 r4 = *reinterpret_cast<const f32x4*>(resa + 8 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[4 * q + r] + b4[r];
+        v = fmaf(sv, r4[r], v);
+        if (relu) v = __builtin_amdgcn_fmed3f(v, 0.f, INFINITY);
+        hv[r] = (_Float16)v;
       }
+      if (PRIV) *reinterpret_cast<f16x4*>(pw0 + (((unsigned)q ^ (((unsigned)li >> 2) & 3u)) << 4)) = hv;
+      else *reinterpret_cast<f16x4*>(sw + ((((unsigned)(4 * wave + q)) ^ ((unsigned)li & 15u)) << 4)) = hv;
+    }
+    if (PRIV) {   // this wave's block: rows 16 i + lane / 4, 16-byte piece lane % 4 of its 64-byte row segment
+      const int m0 = (first + j * step) * S_ROWS;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f16x4 hv;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 8 * q);
-        const f32x4 r4 = *reinterpret_cast<const f32x4*>(resa + 8 * q);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[4 * q + r] + b4[r];
-          v = fmaf(sv, r4[r], v);
-          if (relu) v = __builtin_amdgcn_fmed3f(v, 0.f, INFINITY);
-          hv[r] = (_Float16)v;
-        }
-        *reinterpret_cast<f16x4*>(o + 8 * q) = hv;
+      for (int i = 0; i < 2; ++i) {
+        const unsigned r = 16 * i + (lane >> 2), pc = lane & 3;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(pbase + r * 64 + ((pc ^ ((r >> 2) & 3u)) << 4));
+#if CHIRON_S16_VARIANT & 1
+        if (v[0] == (_Float16)123.25f)
+#endif
+        if (m0 + (int)r < p.M) *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(p.out) + (long)(m0 + r) * p.ldo + 32 * wave + 8 * pc) = v;
       }
     }
   }
+  if (!PRIV) {
+    stage_barrier();
+    f16x8 ov[2];
+    copy_out(mine - 1, ov);
+    store_out(mine - 1, ov);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the tiles past the last one (zeros) before the workgroup's LDS is released
 }
 
 
@@ -297,8 +376,8 @@ bool launch_stream16(const GemmParams& p, hipStream_t stream) {
   const int dev = current_device_index();
   char st = __atomic_load_n(&attr_state[dev], __ATOMIC_ACQUIRE);
   if (st == 0) {
-    const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 1 * S_TILE_H * 2) == hipSuccess &&
-              hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * S_TILE_H * 2) == hipSuccess &&
+    const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (6 * 1 * S_TILE_H + 2 * S_STAGE_H) * 2) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_f16_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 2 * S_TILE_H + S_STAGE_H) * 2) == hipSuccess &&
               hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_f16_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S3_D * S3_TILE_H * 2) == hipSuccess;
     if (!attr_ok) (void)hipGetLastError();   // not sticky: the caller falls back to gemm.hip
     st = attr_ok ? 1 : 2;
@@ -315,9 +394,9 @@ bool launch_stream16(const GemmParams& p, hipStream_t stream) {
     return true;
   }
   if (p.nseg == 1)
-    hipLaunchKernelGGL(conv1x1_f16_stream_kernel<1>, dim3(grid), dim3(64 * (S_NW + S_NP)), (size_t)6 * 1 * S_TILE_H * 2, stream, p);
+    hipLaunchKernelGGL(conv1x1_f16_stream_kernel<1>, dim3(grid), dim3(64 * S_NW), (size_t)(6 * 1 * S_TILE_H + 2 * S_STAGE_H) * 2, stream, p);
   else
-    hipLaunchKernelGGL(conv1x1_f16_stream_kernel<2>, dim3(grid), dim3(64 * (S_NW + S_NP)), (size_t)4 * 2 * S_TILE_H * 2, stream, p);
+    hipLaunchKernelGGL(conv1x1_f16_stream_kernel<2>, dim3(grid), dim3(64 * S_NW), (size_t)(4 * 2 * S_TILE_H + S_STAGE_H) * 2, stream, p);
   return true;
 }
 
