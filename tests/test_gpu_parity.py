@@ -1088,7 +1088,8 @@ def test_f16_recurrence_forms_agree(dna, monkeypatch):
     stats = {k: (float(v.mean()), float(np.quantile(v, 0.999)), float(v.max())) for k, v in dev.items()}
     print(stats)
     assert stats["fused"][2] < 0.08 and stats["wide"][2] < 0.08 and stats["narrow"][2] < 0.08, stats
-    assert stats["fused"][0] < stats["wide"][0] and stats["fused"][1] < stats["wide"][1], stats
+    # z never rounded to f16: the fused form's mean deviation is the smallest; its 99.9 % quantile the same to a percent
+    assert stats["fused"][0] < stats["wide"][0] and stats["fused"][1] < 1.01 * stats["wide"][1], stats
 
 
 def test_f16_config5_full_batch_edit_distance_distribution(dna):
