@@ -1073,11 +1073,23 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w_kernel(const LstmParam
 // ((p0 + p1) + p2) + (p24 + z): agrees with the other forms to rounding, and a row's bits do not depend on its batch.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int W32_PK = 8;   // k-steps of tile 24 per partial wave (waves 0, 1, 2)
+// Round 3, second pass (what the f16 fused kernel taught): on a SIMD that runs fp32 MFMAs, every VALU instruction of a
+// wave64 costs 4 cycles ON TOP of the matrix time, and this kernel spent 340 of them per wave and step.  Now
+//   * the product is computed TRANSPOSED (weight fragment = A operand, h = B operand: a swap of the two arguments): lane
+//     (batch row = lane & 15, unit of the tile = lane >> 4) receives the gates i, j, f, o of ONE cell in its four accumulator
+//     registers -- no transpose through the LDS (3 ds_write_b128 + 12 ds_read_b32 per wave and step) -- and writes h back at
+//     tile * 64 + lane: lane-linear;
+//   * z is read as four dwords per tile (gate g of the lane's cell: [4-row group][dir][g * H + unit][row % 4], 64-byte segments)
+//     instead of one 16-byte column of four rows;
+//   * outputs leave from the completed h tile, 16 bytes (4 units) per thread and step, and the cell phase knows nothing about
+//     sequence lengths (a finished row keeps computing -- rows are independent columns of the product -- and is written as
+//     zeros): no selects, no per-cell address arithmetic, no 4-byte stores;
+//   * tile 24's partial products sit under a wave-uniform branch per 8-k-step chunk, not per k-step.
+#define W32_ZLOAD(dst, vo, off) asm volatile("global_load_dword %0, %1, %2 offset:" #off : "=v"(dst) : "v"(vo), "s"(zs) : "memory")
 
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmParams p) {
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HW32];
-  __shared__ __attribute__((aligned(16))) float xf[(W16_NW * 3 + 1) * W16_XF];
-  __shared__ __attribute__((aligned(16))) float part[3 * 256];    // [partial wave][lane][4 rows]
+  __shared__ __attribute__((aligned(16))) float part[3 * 256];    // [partial wave][lane][4 gates]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1101,10 +1113,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
   }
   for (int i = tid; i < 2 * HW32; i += 64 * W16_NW) hbuf[i] = 0.f;
 
-  const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;
-  const int row = 4 * q + gp;
-  const int brow = g16 * 16 + row;
-  const int lenr = min(p.seq_len[brow], p.T);
+  const int row = lane & 15, q = lane >> 4;          // accumulator lane: batch row, unit of the tile
   int maxlen = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) maxlen = max(maxlen, min(p.seq_len[g16 * 16 + r], p.T));
@@ -1113,54 +1122,61 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
   const unsigned outw = p.ndir * p.H;
   const unsigned zcols = 4 * p.H;
   const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;
-  const unsigned zlane_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 4 * tile0 + u) * 4) * 4;   // + 64 bytes per tile
-  const unsigned z24_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 96 + u) * 4) * 4;
+  // gate g of cell (row, unit 4 T + q): + g * H * 16 bytes (H = 100: 1600), + 64 bytes per tile; the 13-bit immediate reaches
+  // gates 0, 1 from zlo and 2, 3 from zhi
+  const unsigned zlo = (((((g16 * 4 + (row >> 2)) * p.ndir + dir) * zcols + 4 * tile0 + q) * 4) + (row & 3)) * 4;
+  const unsigned zhi = zlo + 2 * 1600;
+  // (tile 24 belongs to wave 7, tile0 = 21: its z is 3 tiles = 192 bytes behind the wave's first tile)
   const unsigned ostep = p.BP * outw;
-  const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;   // + 4 per tile
-  const unsigned olane24 = brow * outw + dir * p.H + 96 + u;
-  const int hw = tile0 * 64 + u * 16 + row;                          // + 64 per tile
-  const int hw24 = 24 * 64 + u * 16 + row;
-  float* const xw = xf + wave * 3 * W16_XF + 4 * lane + 4 * q;
-  const float* const xr = xf + wave * 3 * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
-  float* const xw24 = xf + W16_NW * 3 * W16_XF + 4 * lane + 4 * q;
-  const float* const xr24 = xf + W16_NW * 3 * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
 
-  float c[3] = {0.f, 0.f, 0.f}, hprev[3] = {0.f, 0.f, 0.f};
-  float c24 = 0.f, hprev24 = 0.f;
+  // ---- outputs: the h tile completed in step s - 1 is copied out in step s, 16 bytes (units 4 P .. 4 P + 3 of one row) per
+  //      thread: lane -> row lane & 15 (consecutive lanes read consecutive floats of the [k-step][unit % 4][row] tile), piece
+  //      4 wave + lane / 16: a store instruction covers 64 contiguous bytes of each of 16 rows; pieces 0..24: waves 0..5, a
+  //      quarter of wave 6
+  const int fr = lane & 15, fq = 4 * wave + (lane >> 4);
+  const bool f_on = fq < 25;
+  const int f_len = min(p.seq_len[g16 * 16 + fr], p.T);
+  const unsigned f_out = (g16 * 16 + fr) * outw + dir * p.H + 4 * fq;
+  const float* const f_lds = hbuf + fq * 64 + fr;   // + 16 per unit
+  auto flush = [&](int sp, int buf) {
+    if (f_on) {
+      const bool act = sp < f_len;
+      const unsigned to = (dir == 0 || !act) ? sp : f_len - 1 - sp;
+      const float* hp = f_lds + buf * HW32;
+      f32x4 v = {hp[0], hp[16], hp[32], hp[48]};
+      if (!act) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(p.out + (to * ostep + f_out)) = v;
+    }
+  };
+
+  float c[3] = {0.f, 0.f, 0.f};
+  float c24 = 0.f;
   f32x4 acc24 = {0.f, 0.f, 0.f, 0.f};   // wave 7: last k-step's product + z of the step being finished
   int cur = 0;
 
-  // wave 7: tile 24 of step sp (its partial products are in `part`, acc24 / z24p in registers)
-  auto finish24 = [&](int sp, int buf, bool write_h) {
+  // wave 7: tile 24 of the previous step (its partial products are in `part`, the last k-step's product + z in acc24)
+  auto finish24 = [&](int buf) {
     const f32x4* pp = reinterpret_cast<const f32x4*>(part) + lane;
     f32x4 sum = pp[0] + pp[64];
     sum = sum + pp[128];
-    *reinterpret_cast<f32x4*>(xw24) = sum + acc24;
-    __builtin_amdgcn_wave_barrier();
-    const f32x4 gates = {xr24[0], xr24[4], xr24[8], xr24[12]};
-    const bool act = sp < lenr;
     float hnew;
-    const float cn = lstm_cell(gates, c24, &hnew);
-    c24 = act ? cn : c24;
-    hprev24 = act ? hnew : hprev24;
-    if (write_h) hbuf[buf * HW32 + hw24] = hprev24;
-    const unsigned to = (dir == 0 || !act) ? sp : lenr - 1 - sp;
-    *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + (to * ostep + olane24) * 4u) = act ? hnew : 0.f;
+    c24 = lstm_cell(sum + acc24, c24, &hnew);
+    hbuf[buf * HW32 + 24 * 64 + lane] = hnew;
   };
 
   for (int s = 0; s < maxlen; ++s) {
     const float* zs = p.z + (size_t)s * zstep;
     f32x4 z4[3], z24 = {0.f, 0.f, 0.f, 0.f};
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z4[0]) : "v"(zlane_b), "s"(zs) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(z4[1]) : "v"(zlane_b), "s"(zs) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=v"(z4[2]) : "v"(zlane_b), "s"(zs) : "memory");
-    if (owner24) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(z24) : "v"(z24_b), "s"(zs) : "memory");
+    W32_ZLOAD(z4[0][0], zlo, 0);   W32_ZLOAD(z4[0][1], zlo, 1600);   W32_ZLOAD(z4[0][2], zhi, 0);   W32_ZLOAD(z4[0][3], zhi, 1600);
+    W32_ZLOAD(z4[1][0], zlo, 64);  W32_ZLOAD(z4[1][1], zlo, 1664);   W32_ZLOAD(z4[1][2], zhi, 64);  W32_ZLOAD(z4[1][3], zhi, 1664);
+    W32_ZLOAD(z4[2][0], zlo, 128); W32_ZLOAD(z4[2][1], zlo, 1728);   W32_ZLOAD(z4[2][2], zhi, 128); W32_ZLOAD(z4[2][3], zhi, 1728);
+    if (owner24) {
+      W32_ZLOAD(z24[0], zlo, 192); W32_ZLOAD(z24[1], zlo, 1792); W32_ZLOAD(z24[2], zhi, 192); W32_ZLOAD(z24[3], zhi, 1792);
+    }
     // ---- wave 7 first completes tile 24 of the previous step: h[96..99] of that step is what the last k-step below needs
-    if (owner24 && s > 0) finish24(s - 1, cur, true);
-    // ---- k-steps 0 .. 23: h[0..95] of the previous step (complete since barrier A)
+    if (owner24 && s > 0) finish24(cur);
+    // ---- k-steps 0 .. 23: h[0..95] of the previous step (complete since barrier A), eight at a time, the next eight in flight
     const float* hb = hbuf + cur * HW32 + lane;
-    // h is read eight k-steps at a time, the next eight in flight behind the current products (24 live values would put the
-    // kernel over 168 registers: two waves per SIMD at <= 168 leave room for a conv GEMM wave of another batch on the SIMD)
     f32x4 acc[3], accp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < 3; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1173,12 +1189,18 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
 #pragma unroll
         for (int j = 0; j < 8; ++j) hv[(ch + 1) & 1][j] = hb[(8 * (ch + 1) + j) * 64];
       }
+      if (partial && ch == wave) {   // (wave-uniform: one branch per chunk)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ks = 8 * ch + j;
+        for (int j = 0; j < 8; ++j) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[ch & 1][j], w[n][ks], acc[n], 0, 0, 0);
-        if (partial && ch == wave) accp = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[ch & 1][j], wp[j], accp, 0, 0, 0);
+          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][8 * ch + j], hv[ch & 1][j], acc[n], 0, 0, 0);
+          accp = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j], hv[ch & 1][j], accp, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][8 * ch + j], hv[ch & 1][j], acc[n], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1186,34 +1208,28 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
     // ---- the 25th k-step
     const float h24 = hb[(W32_KS - 1) * 64];
 #pragma unroll
-    for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(h24, w[n][W32_KS - 1], acc[n], 0, 0, 0);
-    if (owner24) {
-      acc24 = __builtin_amdgcn_mfma_f32_16x16x4f32(h24, wp[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(z24), "+v"(acc24) : : "memory");
-      acc24 = acc24 + z24;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z4[0]), "+v"(z4[1]), "+v"(z4[2]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
-    const bool act = s < lenr;
-    const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
-#pragma unroll
-    for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(xw + n * W16_XF) = acc[n] + z4[n];
+    for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][W32_KS - 1], h24, acc[n], 0, 0, 0);
+    if (owner24) acc24 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[0], h24, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    // z has arrived (vmcnt also counts the previous step's output stores: a step old); this step's output stores go out BEHIND
+    // this wait
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(z4[0]), "+v"(z4[1]), "+v"(z4[2]), "+v"(z24) : : "memory");
+    if (owner24) acc24 = acc24 + z24;
+    if (s > 0) flush(s - 1, cur);
     if (partial) reinterpret_cast<f32x4*>(part)[wave * 64 + lane] = accp;
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
-      const float* xs = xr + n * W16_XF;
-      const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};
       float hnew;
-      const float cn = lstm_cell(gates, c[n], &hnew);
-      c[n] = act ? cn : c[n];
-      hprev[n] = act ? hnew : hprev[n];
-      hbuf[(cur ^ 1) * HW32 + hw + 64 * n] = hprev[n];
-      *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + (to * ostep + olane + 4 * n) * 4u) = act ? hnew : 0.f;
+      c[n] = lstm_cell(acc[n] + z4[n], c[n], &hnew);
+      hbuf[(cur ^ 1) * HW32 + (tile0 + n) * 64 + lane] = hnew;
     }
     cur ^= 1;
     __syncthreads();   // barrier A: h[0..95] of this step and the partial products of tile 24 are in place
   }
-  if (owner24 && maxlen > 0) finish24(maxlen - 1, cur, false);
+  if (maxlen > 0) {
+    if (owner24) finish24(cur);
+    __syncthreads();
+    flush(maxlen - 1, cur);
+  }
 
   for (int s = maxlen; s < p.T; ++s)
     for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
