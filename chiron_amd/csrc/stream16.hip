@@ -7,16 +7,13 @@
 //   * the whole weight matrix lives in VGPRs for the lifetime of the (persistent, one per CU) workgroup: wave w owns output
 //     columns 32w .. 32w+31 for every k -- 64 registers per 256-channel K-segment (A operand of v_mfma_f32_32x32x16_f16,
 //     the product is computed transposed, D = W^T x^T, so that a lane ends up with 4 x 4 CONSECUTIVE columns of one row);
-//   * the LDS holds nothing but activation tiles: 32 rows x 256 channels = 16 KB per K-segment, laid out
-//     [k octet][row][8 halves] = the B-operand order (lane (row, kh) reads octet 2 ks + kh: lane-linear 16-byte reads), six
-//     tiles deep (96 KB in flight per CU against 64 KB shared with weights before);
-//   * two PRODUCER waves do nothing but issue the LDS-DMA of tile i + D - 1 and wait for tile i: their vmcnt sees only loads,
-//     which return in order, so a partial s_waitcnt vmcnt(n) is exact; the eight compute waves' vmcnt holds only their stores.
-//     Producer and consumers meet at one s_barrier per tile.
-// Per tile a compute wave issues 16 (32) MFMAs of 32 cycles and 4 eight-byte stores per lane: the kernel is HBM-bound by
-// construction.  NSEG = 2 is conv2c + branch1: two K-segments (the block's conv2b output and the block's input) into one
-// accumulator.  Applicable when the engine is f16, C_in = C_out = 256, stride 1 (res_layer2 / res_layer3 of DNA_default
-// and their RNA counterparts); every other shape keeps gemm.hip.
+//   * the LDS holds nothing but activation tiles (32 rows x 256 channels = 16 KB per K-segment, four to six deep) and the
+//     staging tiles the results leave through; every wave is loader, multiplier and storer (the round-2 form had two producer
+//     waves: see the note in front of the kernel for why they went).
+// Per tile a wave issues 16 (32) MFMAs of 32 cycles: the kernel is HBM-bound by construction.  NSEG = 2 is conv2c + branch1:
+// two K-segments (the block's conv2b output and the block's input) into one accumulator.  Applicable when the engine is f16,
+// C_in = C_out = 256, stride 1 (res_layer2 / res_layer3 of DNA_default and their RNA counterparts); every other shape keeps
+// gemm.hip.
 #include "kernels.h"
 
 #include <algorithm>
@@ -34,9 +31,9 @@ constexpr unsigned S_RECORDS = 0xFFFE0000u;  // every tensor of the engine is sm
 constexpr int S_ROWS = 32;                   // rows per tile
 constexpr int S_C = 256;                     // channels per K-segment = output columns
 constexpr int S_TILE_H = S_ROWS * S_C;       // halves per segment tile (16 KB)
-constexpr int S_NW = 8;                      // compute waves
+constexpr int S_NW = 8;                      // waves per workgroup
 
-// s_barrier between producer and consumer waves.  The compiler does not know that the DMA engine writes the tiles, so it
+// The s_barrier of a tile.  The compiler does not know that the DMA engine writes the tiles, so it
 // must not move an LDS read of the next tile above the barrier (or keep one below it alive across it): the empty asm
 // statements are compiler-only fences, the hardware ordering is the barrier itself (no s_waitcnt vmcnt here -- a
 // __syncthreads() would make every compute wave wait for its own output stores once per tile).
@@ -455,6 +452,7 @@ bool launch_stream16(const GemmParams& p, hipStream_t stream) {
     if (p.seg[i].src == nullptr) return false;   // lifted segments (A computed from the signal) stay with gemm.hip
   if (p.nseg < 1 || p.nseg > 3 || p.K != p.nseg * S_C) return false;
   const bool taps = p.nseg == 3;   // conv2b: the three taps of one tensor
+  if (taps && p.T_out < S_ROWS) return false;   // conv3's position bookkeeping assumes at most one sequence boundary per 32-row tile
   for (int i = 0; i < p.nseg; ++i) {
     const GemmSeg& s = p.seg[i];
     if (s.src == nullptr || s.cin != S_C || s.kpad != S_C || s.stride != 1 || s.time_major || s.w_in != p.T_out) return false;

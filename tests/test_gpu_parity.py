@@ -974,11 +974,14 @@ def _levenshtein(a, b):
 
 
 def test_f16_streaming_conv_equals_tiled_gemm_form(dna, rna, monkeypatch):
-    """stream16.hip (1 x 1 convolutions of res_layer2 / res_layer3 with the weights in registers and the activations streamed
-    through the LDS by producer waves) against the tiled DMA GEMM of gemm.hip (CHIRON_NO_STREAM16=1) in the fp16 engine: the
+    """stream16.hip (the convolutions of res_layer2 / res_layer3 with the weights in registers and the activations streamed
+    through the LDS) against the tiled DMA GEMM of gemm.hip (CHIRON_NO_STREAM16=1) in the fp16 engine: the
     same f16 products accumulated in fp32 in a different order, then rounded to f16 -- logits within 5e-3 (a last-bit flip
     of an f16 activation is 1e-3 relative), batch sizes that leave a partial last 32-row tile, DNA and the RNA topology."""
-    for (spec, w), L, jump, n in ((dna, 400, 390, 37), (rna, 500, 490, 21)):
+    # short segments: many sequence boundaries per 30-row tile of the 1 x 3 kernel (T = 32: one in every tile; T = 30: below the
+    # kernel's minimum, conv2b falls back to the tiled GEMM while the 1 x 1 kernels still stream)
+    for (spec, w), L, jump, n in ((dna, 400, 390, 37), (rna, 500, 490, 21), (dna, 32, 32, 50), (dna, 48, 40, 45), (dna, 100, 90, 41),
+                                  (dna, 30, 30, 20)):
         x, ln = _windows(jump * (n - 1) + 123, L, jump, seed=43)
         out = []
         for off in (False, True):
