@@ -1089,7 +1089,7 @@ constexpr int W32_PK = 8;   // k-steps of tile 24 per partial wave (waves 0, 1, 
 
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmParams p) {
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HW32];
-  __shared__ __attribute__((aligned(16))) float part[3 * 256];    // [partial wave][lane][4 gates]
+  __shared__ __attribute__((aligned(16))) float part[4 * 256];    // [partial wave 0..2 | wave 7's own last-k-step product + z][lane][4 gates]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1133,25 +1133,25 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
   //      thread: lane -> row lane & 15 (consecutive lanes read consecutive floats of the [k-step][unit % 4][row] tile), piece
   //      4 wave + lane / 16: a store instruction covers 64 contiguous bytes of each of 16 rows; pieces 0..24: waves 0..5, a
   //      quarter of wave 6
-  const int fr = lane & 15, fq = 4 * wave + (lane >> 4);
-  const bool f_on = fq < 25;
-  const int f_len = min(p.seq_len[g16 * 16 + fr], p.T);
-  const unsigned f_out = (g16 * 16 + fr) * outw + dir * p.H + 4 * fq;
-  const float* const f_lds = hbuf + fq * 64 + fr;   // + 16 per unit
+  //      (row, piece and the two offsets are recomputed every step from the lane number: the kernel has to stay at 168 registers
+  //      for a conv GEMM wave of another batch to fit next to two of its waves on a SIMD; only the row's length is kept)
+  const int f_len = min(p.seq_len[g16 * 16 + (lane & 15)], p.T);
   auto flush = [&](int sp, int buf) {
-    if (f_on) {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));   // not hoisted out of the step loop
+    const int fr = lo & 15, fq = 4 * wave + (lo >> 4);
+    if (fq < 25) {
       const bool act = sp < f_len;
       const unsigned to = (dir == 0 || !act) ? sp : f_len - 1 - sp;
-      const float* hp = f_lds + buf * HW32;
+      const float* hp = hbuf + buf * HW32 + fq * 64 + fr;   // + 16 per unit
       f32x4 v = {hp[0], hp[16], hp[32], hp[48]};
       if (!act) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(p.out + (to * ostep + f_out)) = v;
+      *reinterpret_cast<f32x4*>(p.out + (to * ostep + (g16 * 16 + fr) * outw + dir * p.H + 4 * fq)) = v;
     }
   };
 
   float c[3] = {0.f, 0.f, 0.f};
   float c24 = 0.f;
-  f32x4 acc24 = {0.f, 0.f, 0.f, 0.f};   // wave 7: last k-step's product + z of the step being finished
   int cur = 0;
 
   // wave 7: tile 24 of the previous step (its partial products are in `part`, the last k-step's product + z in acc24)
@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
     f32x4 sum = pp[0] + pp[64];
     sum = sum + pp[128];
     float hnew;
-    c24 = lstm_cell(sum + acc24, c24, &hnew);
+    c24 = lstm_cell(sum + pp[192], c24, &hnew);   // pp[192]: wave 7's own last-k-step product + z (kept in the LDS, not in registers)
     hbuf[buf * HW32 + 24 * 64 + lane] = hnew;
   };
 
@@ -1209,11 +1209,12 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
     const float h24 = hb[(W32_KS - 1) * 64];
 #pragma unroll
     for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][W32_KS - 1], h24, acc[n], 0, 0, 0);
+    f32x4 acc24 = {0.f, 0.f, 0.f, 0.f};
     if (owner24) acc24 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[0], h24, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     // z has arrived (vmcnt also counts the previous step's output stores: a step old); this step's output stores go out BEHIND
     // this wait
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(z4[0]), "+v"(z4[1]), "+v"(z4[2]), "+v"(z24) : : "memory");
-    if (owner24) acc24 = acc24 + z24;
+    if (owner24) reinterpret_cast<f32x4*>(part)[192 + lane] = acc24 + z24;
     if (s > 0) flush(s - 1, cur);
     if (partial) reinterpret_cast<f32x4*>(part)[wave * 64 + lane] = accp;
 #pragma unroll
