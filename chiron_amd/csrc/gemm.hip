@@ -184,6 +184,9 @@ __device__ __forceinline__ void gemm_epilogue_zrows_t(const GemmParams& p, f32x1
   };
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
+    // one register quad at a time: with the four quads' addresses and conversions scheduled together the epilogue, not the
+    // main loop (162), set the kernel's register count (186 .. 205) -- and 176 is what fits next to two recurrence waves
+    __builtin_amdgcn_sched_barrier(0);
     const int dm = wave * 32 + 8 * q + 4 * kh;  // first of 4 consecutive rows
     if (m0 + dm >= p.M) continue;
     int t, b;
@@ -785,27 +788,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
               dma_piece<0>(L, q, a_dst, b_dst);
           }
         };
-        f32x16 ini[NNI];
         if (FS && C == 0) {
-          // C operand of the tile's first MFMAs: this lane's 16 shift values per 32-column block
+          // The previous tile's epilogue is issued HERE, after this tile's first barrier: the barrier's
+          // vmcnt(0) then only ever waits for DMA issued a whole chunk earlier, never for fresh stores.
+          // (Round 3: BEFORE the shift vectors below are built, so that these take the registers the epilogue has just
+          // released -- built first, the projection's 5 x 16 of them sat next to its 80 accumulators: 226 .. 237 registers,
+          // and no such wave fits next to two recurrence waves on a SIMD; now it does.)
+          if (have_prev) epilogue(pm0, pn0);
+          asm volatile("" ::: "memory");
+          // C operand of the tile's first MFMAs: this lane's 16 shift values per 32-column block, written INTO the accumulators
+          // (a separate vector is not coalesced with them by the register allocator: 80 more live registers in the projection)
 #pragma unroll
           for (int ni = 0; ni < NNI; ++ni) {
             if (ZOUT) {
               const float sh = shl[n0 + ni * 32 + li];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) ini[ni][r] = sh;
+              for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = sh;
             } else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(shl + n0 + wn * 64 + ni * 32 + 8 * q + 4 * kh);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ini[ni][4 * q + r] = sh[r];
+                for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) acc[mi][ni][4 * q + r] = sh[r];
               }
             }
           }
-          // The previous tile's epilogue is issued HERE, after this tile's first barrier: the barrier's
-          // vmcnt(0) then only ever waits for DMA issued a whole chunk earlier, never for fresh stores.
-          if (have_prev) epilogue(pm0, pn0);
         }
         {
           const float* a0 = As + buf * DTILE_F + (wm * (NMI * 32) + li) * GEMM_BK;
@@ -836,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                 for (int ni = 0; ni < NNI; ++ni) {
                   const f16x8 xah = __builtin_bit_cast(f16x8, ah[mi]), xal = __builtin_bit_cast(f16x8, al[mi]);
                   const f16x8 xbh = __builtin_bit_cast(f16x8, bh[ni]), xbl = __builtin_bit_cast(f16x8, bl[ni]);
-                  f32x16 c = (FS && C == 0 && st == 0) ? ini[ni] : acc[mi][ni];
+                  f32x16 c = acc[mi][ni];
                   if (ZOUT) {
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal, xbh, c, 0, 0, 0);   // small terms first
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, c, 0, 0, 0);
@@ -873,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
               for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NNI; ++ni) {
-                  const f32x16 c = (FS && C == 0 && g == 0) ? ini[ni] : acc[mi][ni];
+                  const f32x16 c = acc[mi][ni];
                   const f16x8 ah = __builtin_bit_cast(f16x8, a[mi]), bh = __builtin_bit_cast(f16x8, b[ni]);
                   acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0)
                                      : __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, c, 0, 0, 0);
@@ -886,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                 for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
                   for (int ni = 0; ni < NNI; ++ni) {
-                    const f32x16 c = (FS && C == 0 && g == 0 && j == 0) ? ini[ni] : acc[mi][ni];
+                    const f32x16 c = acc[mi][ni];
                     acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], c, 0, 0, 0)
                                        : __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][j], a[mi][j], c, 0, 0, 0);
                   }
