@@ -542,21 +542,57 @@ extern "C" chiron_status chiron_write_signal_text(const char* path, const float*
   if (!path || (!v && n > 0) || n < 0) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_write_signal_text: bad argument");
   const char* dl = delimiter ? delimiter : "\n";
   const size_t dn = strlen(dl);
+  // 100 000 samples per read and one such file per read: this formatter is on the host's critical path behind the fp16 engine
+  // (pointer writes into one buffer, two digits per division by 100)
+  static const char pairs[] =
+      "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869"
+      "707172737475767778798081828384858687888990919293949596979899";
   std::string buf;
-  buf.reserve((size_t)n * (6 + dn) + 16);
-  char tmp[24];
+  buf.resize((size_t)n * (20 + dn) + 16);
+  char* out = &buf[0];
   for (int64_t k = 0; k < n; ++k) {
     const float x = v[k];
-    const long long iv = (long long)x;
-    if ((float)iv != x || x > 9.0e15f || x < -9.0e15f) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_write_signal_text: sample %lld (%g) is not an integer", (long long)k, (double)x);
-    if (k) buf.append(dl, dn);
-    // small fast integer formatter
+    long long iv;
+    if (x > -2.0e9f && x < 2.0e9f) {
+      const int i32 = (int)x;              // every real signal
+      if ((float)i32 != x) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_write_signal_text: sample %lld (%g) is not an integer", (long long)k, (double)x);
+      iv = i32;
+    } else {
+      iv = (long long)x;
+      if ((float)iv != x || x > 9.0e15f || x < -9.0e15f || x != x) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_write_signal_text: sample %lld (%g) is not an integer", (long long)k, (double)x);
+    }
+    if (k) {
+      if (dn == 1) {
+        *out++ = dl[0];
+      } else {
+        memcpy(out, dl, dn);
+        out += dn;
+      }
+    }
     unsigned long long a = iv < 0 ? (unsigned long long)(-iv) : (unsigned long long)iv;
+    if (iv < 0) *out++ = '-';
+    char tmp[24];
     int len = 0;
-    do { tmp[len++] = (char)('0' + a % 10); a /= 10; } while (a);
-    if (iv < 0) tmp[len++] = '-';
-    while (len) buf.push_back(tmp[--len]);
+    if (a < 4000000000ull) {          // every real signal: 32-bit arithmetic
+      unsigned u = (unsigned)a;
+      while (u >= 100) {
+        const unsigned r = u % 100;
+        u /= 100;
+        tmp[len++] = pairs[2 * r + 1];
+        tmp[len++] = pairs[2 * r];
+      }
+      if (u >= 10) {
+        tmp[len++] = pairs[2 * u + 1];
+        tmp[len++] = pairs[2 * u];
+      } else {
+        tmp[len++] = (char)('0' + u);
+      }
+    } else {
+      do { tmp[len++] = (char)('0' + a % 10); a /= 10; } while (a);
+    }
+    while (len) *out++ = tmp[--len];
   }
+  buf.resize((size_t)(out - &buf[0]));
   FILE* fo = fopen(path, "wb");
   if (!fo) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_write_signal_text: cannot open %s", path);
   const size_t w = buf.empty() ? 0 : fwrite(buf.data(), 1, buf.size(), fo);
