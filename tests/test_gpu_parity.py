@@ -1095,6 +1095,49 @@ def test_f16_recurrence_forms_agree(dna, monkeypatch):
     assert stats["fused"][0] < stats["wide"][0] and stats["fused"][1] < 1.01 * stats["wide"][1], stats
 
 
+def test_f16_config5_full_batch_properties(dna, monkeypatch):
+    """BASELINE configs[4] size (fp16, 4096 windows): the properties of the fp32 full-batch test for the fp16 engine's own kernels --
+    32-row fused recurrence workgroups (one per CU), streaming convolutions with 200 .. 430 tiles per workgroup.
+    (a) rows are independent: a permuted batch gives bit-identical rows; (b) two slots in flight do not disturb each other;
+    (c) the greedy decode equals the oracle's decode of the engine's logits; (d) the other kernel forms of the same engine
+    (tiled GEMM convolutions + projection GEMM and z + 16-row recurrence) agree to 1e-2 on logits at this size too."""
+    spec, w = dna
+    L, B = 400, 4096
+    x, ln = _windows(390 * (B - 1) + 133, L, 390, seed=47)
+    assert x.shape[0] == B
+    ln = ln.copy()
+    rng = np.random.RandomState(8)
+    cut = rng.choice(B, 300, replace=False)
+    ln[cut] = rng.randint(0, L + 1, size=300)
+    for b in cut:
+        x[b, ln[b]:] = 0
+    for v in ("CHIRON_NO_STREAM16", "CHIRON_LSTM16_UNFUSED", "CHIRON_LSTM16_PAIR"):
+        monkeypatch.delenv(v, raising=False)
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=2, dtype="fp16") as eng:
+        sl = ca.seq_len_for_engine(ln, eng.ratio)
+        res = eng.infer(x, sl, want_prob=True, want_logits=True)
+        assert np.isfinite(res.logits).all()
+        _check_decode(res, res.logits, sl, B)
+        perm = rng.permutation(B)
+        rp = eng.infer(x[perm], sl[perm], want_logits=True, slot=1)
+        assert np.array_equal(rp.logits, res.logits[perm])
+        eng.submit(0, x, sl, want_logits=True)
+        eng.submit(1, x[perm], sl[perm], want_logits=True)
+        a, b2 = eng.collect(0), eng.collect(1)
+        assert np.array_equal(a.logits, res.logits) and np.array_equal(b2.logits, rp.logits)
+    monkeypatch.setenv("CHIRON_NO_STREAM16", "1")
+    monkeypatch.setenv("CHIRON_LSTM16_UNFUSED", "1")
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, dtype="fp16") as eng:
+        other = eng.infer(x, sl, want_logits=True)
+    for v in ("CHIRON_NO_STREAM16", "CHIRON_LSTM16_UNFUSED"):
+        monkeypatch.delenv(v, raising=False)
+    T = res.logits.shape[1]
+    mask = np.arange(T)[None, :] < sl[:, None]
+    d = np.abs(res.logits - other.logits)[mask]
+    assert d.max() < 1e-2, d.max()
+    assert np.array_equal(res.logits[~mask].view(np.uint32), other.logits[~mask].view(np.uint32))   # padded frames: the FC bias path, bit for bit
+
+
 @pytest.mark.parametrize("regime", ["synthetic", "peaked"])
 def test_f16_config5_full_batch_edit_distance_distribution(dna, regime):
     """BASELINE configs[4] at its real size: DNA_default, fp16 conv + LSTM / fp32 CTC, batch 4096, against the fp32 engine
