@@ -1099,7 +1099,8 @@ def test_f16_config5_full_batch_properties(dna, monkeypatch):
     """BASELINE configs[4] size (fp16, 4096 windows): the properties of the fp32 full-batch test for the fp16 engine's own kernels --
     32-row fused recurrence workgroups (one per CU), streaming convolutions with 200 .. 430 tiles per workgroup.
     (a) rows are independent: a permuted batch gives bit-identical rows; (b) two slots in flight do not disturb each other;
-    (c) the greedy decode equals the oracle's decode of the engine's logits; (d) the other kernel forms of the same engine
+    (c) the greedy decode equals the oracle's decode of the engine's logits; (d) 16-row recurrence workgroups give the same bits
+    as the 32-row ones; (e) the other kernel forms of the same engine
     (tiled GEMM convolutions + projection GEMM and z + 16-row recurrence) agree to 1e-2 on logits at this size too."""
     spec, w = dna
     L, B = 400, 4096
@@ -1125,6 +1126,12 @@ def test_f16_config5_full_batch_properties(dna, monkeypatch):
         eng.submit(1, x[perm], sl[perm], want_logits=True)
         a, b2 = eng.collect(0), eng.collect(1)
         assert np.array_equal(a.logits, res.logits) and np.array_equal(b2.logits, rp.logits)
+    # 16-row workgroups (two rounds of 256) instead of the 32-row ones this batch size selects: the same arithmetic per row
+    monkeypatch.setenv("CHIRON_LSTM16_PAIR", "0")
+    with ca.Engine(spec, w, max_batch=B, segment_len=L, dtype="fp16") as eng:
+        single = eng.infer(x, sl, want_logits=True)
+    monkeypatch.delenv("CHIRON_LSTM16_PAIR", raising=False)
+    assert np.array_equal(single.logits, res.logits)
     monkeypatch.setenv("CHIRON_NO_STREAM16", "1")
     monkeypatch.setenv("CHIRON_LSTM16_UNFUSED", "1")
     with ca.Engine(spec, w, max_batch=B, segment_len=L, dtype="fp16") as eng:
