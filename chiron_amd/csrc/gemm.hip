@@ -585,7 +585,10 @@ __device__ __forceinline__ void dma_issue(const DmaSrc& L, float* a_dst, float* 
 // count is not a multiple of 32 (its last chunk selects per lane against the K tail).
 // MODE 0: fp32 operands (v_mfma_f32_32x32x2_f32).  1: IEEE halves (v_mfma_f32_32x32x16_f16).  2: fp32 values carried as
 // exact hi + lo half pairs ("split" format), three f16 MFMAs per product term set: hi*hi + hi*lo + lo*hi, fp32 accumulate.
-template <bool ZOUT, bool RES, int CPS, bool TAIL, int MODE = 0>
+// ONESEG: the launch has a single K-segment (every fp32 projection of the DNA stack): known at compile time, the per-row
+// (batch, frame, valid) triples of a tile die as soon as its DMA offsets are built instead of living through the tile for a
+// next segment that never comes -- part of getting the projection under 176 registers.
+template <bool ZOUT, bool RES, int CPS, bool TAIL, int MODE = 0, bool ONESEG = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p) {
   constexpr bool F16 = MODE == 1;
   constexpr bool SPLIT = MODE == 2;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   const int nblocks_n = (p.N + BN - 1) / BN;
   const int mblocks = (p.M + GEMM_BM - 1) / GEMM_BM;
   const int total_ids = ((mblocks + 7) / 8) * 8 * nblocks_n;
-  const int nseg = p.nseg;
+  const int nseg = ONESEG ? 1 : p.nseg;
 
   auto tile_of = [&](int id, int& m0, int& n0) -> bool {
     const int xcd = id & 7;
@@ -821,6 +824,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
         {
           const float* a0 = As + buf * DTILE_F + (wm * (NMI * 32) + li) * GEMM_BK;
           const float* b0 = Bs + buf * BTILE_F + (wn * (NNI * 32) + li) * GEMM_BK;
+          // fragment slot of k-group g: fslot[g] = fslot[0] ^ 8 g (floats).  Derived per chunk from ONE opaque register: hoisted,
+          // the eight (operand, g) addresses of both buffers are sixteen registers held for the whole kernel, and the projection
+          // has to come down to 176 to fit next to two recurrence waves on a SIMD
+          int fs0 = fslot[0];
+          asm volatile("" : "+v"(fs0));
+          auto fsl = [&](int g) -> int { return fs0 ^ (8 * g); };
           if (SPLIT) {
             // A 128-byte row chunk = 32 elements: slots 0-3 hold the hi halves of elements 0-7 / 8-15 / 16-23 / 24-31,
             // slots 4-7 the lo halves.  k-step s (16 elements) uses hi slot 2s+kh and lo slot 4+2s+kh, i.e. the fp32
@@ -833,13 +842,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
               f32x4 ah[NMI], al[NMI], bh[NNI], bl[NNI];
 #pragma unroll
               for (int mi = 0; mi < NMI; ++mi) {
-                ah[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st]);
-                al[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[st + 2]);
+                ah[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fsl(st));
+                al[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fsl(st + 2));
               }
 #pragma unroll
               for (int ni = 0; ni < NNI; ++ni) {
-                bh[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[st]);
-                bl[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[st + 2]);
+                bh[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fsl(st));
+                bl[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fsl(st + 2));
               }
 #pragma unroll
               for (int mi = 0; mi < NMI; ++mi)
@@ -872,9 +881,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
             }
             f32x4 a[NMI], b[NNI];
 #pragma unroll
-            for (int mi = 0; mi < NMI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fslot[g]);
+            for (int mi = 0; mi < NMI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * GEMM_BK + fsl(g));
 #pragma unroll
-            for (int ni = 0; ni < NNI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fslot[g]);
+            for (int ni = 0; ni < NNI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * GEMM_BK + fsl(g));
             if (F16) {
               // 16 bytes = the 8 halves of one k-step of v_mfma_f32_32x32x16_f16 (lanes 0-31: k 0-7, lanes 32-63: k 8-15)
 #pragma unroll
@@ -976,6 +985,18 @@ static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s
       }
     }
     return false;
+  }
+  if constexpr (ZOUT) {
+    if (p.nseg == 1) {
+      if (kpad == 256 && !tail) {
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 8, false, 0, true>), grid, block, 0, stream, p);
+        return true;
+      }
+      if (kpad == 224 && tail) {
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 7, true, 0, true>), grid, block, 0, stream, p);
+        return true;
+      }
+    }
   }
   if (kpad == 256 && !tail) {
     hipLaunchKernelGGL((gemm_f32_dma_kernel<ZOUT, RES, 8, false>), grid, block, 0, stream, p);
