@@ -951,6 +951,16 @@ static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s
   if (p.f16 == 2) {
     // split format: 4-byte units = elements, rows stored zero padded to whole 32-element blocks
     if (!ZOUT && p.N % GEMM_BN) return false;
+    if constexpr (ZOUT) {
+      if (p.nseg == 1 && kpad == 256 && !tail) {
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 8, false, 2, true>), grid, block, 0, stream, p);
+        return true;
+      }
+      if (p.nseg == 1 && kpad == 224 && tail) {
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 7, true, 2, true>), grid, block, 0, stream, p);
+        return true;
+      }
+    }
     if (kpad == 256 && !tail) {
       hipLaunchKernelGGL((gemm_f32_dma_kernel<ZOUT, RES, 8, false, 2>), grid, block, 0, stream, p);
       return true;
