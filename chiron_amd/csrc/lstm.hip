@@ -54,13 +54,15 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 // q = (i, j, f, o) pre-activations, c = previous cell state  ->  new cell state; *h_out = new output
 __device__ __forceinline__ float lstm_cell(f32x4 q, float c, float* h_out) {
-  const f32x2 e_if = (f32x2){q[0], q[2]} * (f32x2){-LOG2E, -LOG2E};
-  const f32x2 e_oj = (f32x2){q[3], q[1]} * (f32x2){-LOG2E, 2.0f * LOG2E};
-  const f32x2 d_if = (f32x2){__builtin_amdgcn_exp2f(e_if[0]), __builtin_amdgcn_exp2f(e_if[1])} + (f32x2){1.0f, 1.0f};
-  const f32x2 d_oj = (f32x2){__builtin_amdgcn_exp2f(e_oj[0]), __builtin_amdgcn_exp2f(e_oj[1])} + (f32x2){1.0f, 1.0f};
-  const float si = __builtin_amdgcn_rcpf(d_if[0]), sf = __builtin_amdgcn_rcpf(d_if[1]);
-  const float so = __builtin_amdgcn_rcpf(d_oj[0]);
-  const float tj = fmaf(-2.0f, __builtin_amdgcn_rcpf(d_oj[1]), 1.0f);
+  // the pairs are the register-adjacent ones, (i, j) and (f, o): the accumulators of the 16-row forms deliver the four gates in
+  // consecutive registers, and pairing (i, f) / (o, j) cost five moves per cell to build the packed operands
+  const f32x2 e_ij = (f32x2){q[0], q[1]} * (f32x2){-LOG2E, 2.0f * LOG2E};
+  const f32x2 e_fo = (f32x2){q[2], q[3]} * (f32x2){-LOG2E, -LOG2E};
+  const f32x2 d_ij = (f32x2){__builtin_amdgcn_exp2f(e_ij[0]), __builtin_amdgcn_exp2f(e_ij[1])} + (f32x2){1.0f, 1.0f};
+  const f32x2 d_fo = (f32x2){__builtin_amdgcn_exp2f(e_fo[0]), __builtin_amdgcn_exp2f(e_fo[1])} + (f32x2){1.0f, 1.0f};
+  const float si = __builtin_amdgcn_rcpf(d_ij[0]), sf = __builtin_amdgcn_rcpf(d_fo[0]);
+  const float so = __builtin_amdgcn_rcpf(d_fo[1]);
+  const float tj = fmaf(-2.0f, __builtin_amdgcn_rcpf(d_ij[1]), 1.0f);
   const float cn = fmaf(sf, c, si * tj);
   *h_out = so * fast_tanh(cn);
   return cn;
@@ -1177,9 +1179,9 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
     if (owner24 && s > 0) finish24(cur);
     // ---- k-steps 0 .. 23: h[0..95] of the previous step (complete since barrier A), eight at a time, the next eight in flight
     const float* hb = hbuf + cur * HW32 + lane;
-    f32x4 acc[3], accp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < 3; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (the first product of a chain takes a literal zero as its C operand: no accumulator is cleared with moves)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[3], accp = zero4;
     float hv[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) hv[0][j] = hb[j * 64];
@@ -1193,14 +1195,14 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
-          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][8 * ch + j], hv[ch & 1][j], acc[n], 0, 0, 0);
-          accp = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j], hv[ch & 1][j], accp, 0, 0, 0);
+          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][8 * ch + j], hv[ch & 1][j], (ch == 0 && j == 0) ? zero4 : acc[n], 0, 0, 0);
+          accp = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j], hv[ch & 1][j], j == 0 ? zero4 : accp, 0, 0, 0);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][8 * ch + j], hv[ch & 1][j], acc[n], 0, 0, 0);
+          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][8 * ch + j], hv[ch & 1][j], (ch == 0 && j == 0) ? zero4 : acc[n], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
