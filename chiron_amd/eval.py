@@ -454,7 +454,12 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
     # Here: a pool of reader threads parses / windows the next files while the engine works (the native text parser
     # and zlib release the GIL), and finished reads are assembled and written on a second pool; the main thread only
     # packs batches and talks to the engine.  Batches are packed in file order, so results do not depend on timing.
-    n_threads = max(1, int(getattr(FLAGS, "threads", 0) or 4))
+    n_threads = int(getattr(FLAGS, "threads", 0) or 0)
+    if n_threads <= 0:
+        # default: a quarter of this rank's share of the host's cores, between 4 and 12 (behind the fp16 engine the fast5 side --
+        # inflate + the raw/*.signal copy of every read -- needs 6 .. 8 reader threads to keep up; 8 ranks on a 128-core node: 4)
+        ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+        n_threads = min(12, max(4, (os.cpu_count() or 16) // (4 * ranks_here)))
     readers = ThreadPoolExecutor(max_workers=n_threads)
     # Finishing (base strings, consensus vote, quality string, three files per read) is Python + numpy + native calls: as
     # threads it is bound by the GIL at a few hundred reads per second, enough for the fp32 engine.  FLAGS.finish_procs > 0
