@@ -171,6 +171,8 @@ struct ProfEvent {
 
 struct Slot {
   hipStream_t stream = nullptr;
+  unsigned long long* tile_ctr = nullptr;   // device [8]: per-XCD tile counters of the DMA GEMM (GemmParams::tile_ctr), never reset
+  unsigned long long tile_base = 0;         // host: the number the stream's next GEMM launch starts at
   float* sig = nullptr;
   int32_t* seq = nullptr;
   float* act[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 3 in population mode, 5 in batch-BN mode
@@ -223,6 +225,7 @@ struct chiron_engine {
   int maxB = 0, BP = 0;
   bool stream32 = true;           // fp32: 1 x 1 convolutions on the weight-stationary streaming kernel (CHIRON_NO_STREAM32=1: gemm.hip, A/B switch)
   bool stream16 = true;           // f16: 1 x 1 convolutions on the streaming kernel (CHIRON_NO_STREAM16=1: gemm.hip, A/B switch)
+  bool dyn_tiles = true;          // DMA GEMM: tiles handed out by per-XCD counters instead of fixed shares (CHIRON_STATIC_TILES=1: off)
   int lstm16_pair = -1;           // f16 fused recurrence, two 16-row groups per workgroup: 1 always, 0 never (CHIRON_LSTM16_PAIR), -1 when single groups would not fit one round
   bool lstm16_fused = false;      // f16: x-projection inside the recurrence (whole 16-row groups that fill the CUs)
   bool lstm16_narrow = false;     // A/B switch: f16 recurrence on 4-row workgroups only
@@ -764,6 +767,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
     cmax = std::max<size_t>(cmax, b.c);
   }
   chiron_status st;
+  if ((st = dev_alloc(e, (void**)&s->tile_ctr, 8 * sizeof(unsigned long long), true))) return st;
   if ((st = dev_alloc(e, (void**)&s->sig, B * L * 4, true))) return st;
   if ((st = dev_alloc(e, (void**)&s->seq, BP * 4, true))) return st;
   for (int i = 0; i < (e->bn_batch ? 5 : 3); ++i)
@@ -851,6 +855,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->lstm16_pair = getenv("CHIRON_LSTM16_PAIR") ? atoi(getenv("CHIRON_LSTM16_PAIR")) : -1;
   e->stream16 = getenv("CHIRON_NO_STREAM16") == nullptr;
   e->stream32 = getenv("CHIRON_NO_STREAM32") == nullptr;
+  e->dyn_tiles = getenv("CHIRON_STATIC_TILES") == nullptr;   // A/B switch: fixed tile shares per workgroup
   {
     // f16 engines run the x-projection inside the recurrence (lstm16f_kernel) from 64 sixteen-row workgroups up (B >= 512:
     // a workgroup alone on its CU takes 0.69 ms for T = 400 whatever the batch, the projection GEMMs + the 4-row recurrence
@@ -940,6 +945,12 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
 // Segments are filled in ELEMENTS; the f16 kernels address in 4-byte units (see GemmParams::f16).
 static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
   if (!e->f16 && !e->split && e->stream32 && launch_stream32(g, stream)) return true;   // fp32 256 -> 256 channel 1 x 1 convolutions
+  if (e->dyn_tiles)
+    for (Slot& sl : e->slots)
+      if (sl.stream == stream) {   // the stream's tile counters (dynamic tile scheduling of the DMA GEMM)
+        g.tile_ctr = sl.tile_ctr;
+        g.tile_base_host = &sl.tile_base;
+      }
   if (e->split) g.f16 = 2;  // same 4-byte element units as fp32; only the content of the 128-byte blocks differs
   if (e->f16) {
     if (e->stream16 && launch_stream16(g, stream)) return true;   // 256 -> 256 channel 1 x 1 convolutions: streaming kernel

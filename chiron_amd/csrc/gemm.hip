@@ -708,8 +708,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     for (int q = 0; q < NP; ++q) tail_piece(c, cin, q, a_dst, b_dst);
   };
 
+  // ---- tile ids: static shares (stride gridDim.x) or, with counters, the next slot of this XCD (GemmParams::tile_ctr)
+  __shared__ int sh_next;
+  const bool dyn = p.tile_ctr != nullptr && CPS >= 3;   // the number is fetched in chunk 0, published in chunk 1, read in chunk 2
+  const int my_xcd = blockIdx.x & 7;
+  const unsigned slots_per_xcd = (unsigned)(total_ids >> 3);
+  unsigned long long grabbed = 0;   // thread 0: the counter value behind the next tile
+  auto issue_grab = [&]() {
+    if (tid == 0) grabbed = atomicAdd(p.tile_ctr + my_xcd, 1ull);
+  };
+  auto decode_grab = [&]() -> int {   // thread 0: the tile id behind `grabbed` (slots past the last row block are skipped)
+    for (;;) {
+      const unsigned long long v = grabbed - p.tile_base;
+      if (v >= slots_per_xcd) return total_ids;
+      const int id = (int)((unsigned)v << 3) | my_xcd;
+      int mm, nn;
+      if (tile_of(id, mm, nn)) return id;
+      grabbed = atomicAdd(p.tile_ctr + my_xcd, 1ull);
+    }
+  };
   int c_id = blockIdx.x;
-  {
+  if (dyn) {
+    issue_grab();
+    if (tid == 0) sh_next = decode_grab();
+    __syncthreads();
+    c_id = sh_next;
+    if (c_id >= total_ids) return;
+  } else {
     int m0, n0;
     if (c_id >= total_ids) return;
     if (!tile_of(c_id, m0, n0)) c_id = next_valid(c_id);
@@ -750,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   while (c_id < total_ids) {
     int m0, n0;
     tile_of(c_id, m0, n0);
-    const int n_id = next_valid(c_id);
+    int n_id = dyn ? total_ids : next_valid(c_id);
     int k0 = 0;
 
     auto segment = [&](auto first_tag, int sgi) {
@@ -762,6 +787,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
       auto chunk = [&](auto cc) {
         constexpr int C = decltype(cc)::value;
         __syncthreads();  // chunk in `buf` has landed (vmcnt drained before the barrier); buf^1 is free
+        if (FS && dyn) {   // the next tile's number: requested, published one barrier later (it has returned by then), read after the next
+          if (C == 0) issue_grab();
+          if (C == 1 && tid == 0) sh_next = decode_grab();
+          if (C == 2) n_id = sh_next;
+        }
         float* a_dst = As + (buf ^ 1) * DTILE_F + wave * 1024;  // wave-uniform bases; lanes land at +16 B each
         float* b_dst = Bs + (buf ^ 1) * BTILE_F + wave * (BTILE_F / 4);
         // The NP (8 or 9) DMA instructions of the next chunk are interleaved with the first MFMAs below instead of
@@ -1025,7 +1055,8 @@ static bool launch_dma(const GemmParams& p, dim3 grid, dim3 block, hipStream_t s
   return false;
 }
 
-bool launch_gemm(const GemmParams& p, hipStream_t stream) {
+bool launch_gemm(const GemmParams& p0, hipStream_t stream) {
+  GemmParams p = p0;
   const int nblocks_n = (p.N + GEMM_BN - 1) / GEMM_BN;
   const int mblocks = (p.M + GEMM_BM - 1) / GEMM_BM;
   const int total_ids = ((mblocks + 7) / 8) * 8 * nblocks_n;
@@ -1037,22 +1068,33 @@ bool launch_gemm(const GemmParams& p, hipStream_t stream) {
   // projections run 128 x 160 tiles on the DMA kernel
   const int total_z = ((mblocks + 7) / 8) * 8 * ((p.N + 159) / 160);
   const dim3 grid_z(std::min((2 * n_cu / 8) * 8, total_z));
+  // dynamic tile numbers (GemmParams::tile_ctr): the DMA kernel uses them when a segment has three chunks or more; a launch
+  // takes slots-per-XCD + workgroups-per-XCD numbers from every counter
+  const bool zout = p.out_mode == 1;
+  const bool dyn = p.tile_ctr != nullptr && p.tile_base_host != nullptr && p.seg[0].src != nullptr && p.seg[0].kpad / GEMM_BK >= 3 &&
+                   (zout ? grid_z.x : grid.x) % 8 == 0;
+  if (dyn) p.tile_base = *p.tile_base_host;
+  else p.tile_ctr = nullptr;
+  auto advance = [&](bool launched) {
+    if (launched && dyn) *p.tile_base_host += (unsigned long long)((zout ? total_z : total_ids) / 8 + (zout ? grid_z.x : grid.x) / 8);
+    return launched;
+  };
   if (p.f16) {  // halves: only the DMA kernels exist
     if (p.seg[0].src == nullptr) return false;
-    if (p.out_mode == 1) return launch_dma<true, false>(p, grid_z, block, stream);
-    if (p.res_a != nullptr) return launch_dma<false, true>(p, grid, block, stream);
-    return launch_dma<false, false>(p, grid, block, stream);
+    if (p.out_mode == 1) return advance(launch_dma<true, false>(p, grid_z, block, stream));
+    if (p.res_a != nullptr) return advance(launch_dma<false, true>(p, grid, block, stream));
+    return advance(launch_dma<false, false>(p, grid, block, stream));
   }
   if (p.seg[0].src == nullptr) {  // lifted signal: A is computed in the loader
     hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, block, 0, stream, p);
   } else if (p.out_mode == 1) {
-    if (!launch_dma<true, false>(p, grid_z, block, stream))
+    if (!advance(launch_dma<true, false>(p, grid_z, block, stream)))
       hipLaunchKernelGGL((gemm_f32_kernel<false, true, false>), grid, block, 0, stream, p);
   } else if (p.res_a != nullptr) {
-    if (!launch_dma<false, true>(p, grid, block, stream))
+    if (!advance(launch_dma<false, true>(p, grid, block, stream)))
       hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, block, 0, stream, p);
   } else {
-    if (!launch_dma<false, false>(p, grid, block, stream))
+    if (!advance(launch_dma<false, false>(p, grid, block, stream)))
       hipLaunchKernelGGL((gemm_f32_kernel<false, false, false>), grid, block, 0, stream, p);
   }
   return true;

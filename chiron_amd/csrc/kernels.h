@@ -93,6 +93,15 @@ struct GemmParams {
   // shift and the z output stay fp32.
   int f16;
   int z_f16;  // out_mode 1: z is written as halves (f16 engine: the recurrence converts back; halves the z traffic)
+  // Dynamic tile scheduling of the DMA kernel (round 3): eight counters in device memory, one per XCD (a workgroup's XCD is
+  // blockIdx.x & 7, as in the static mapping).  A workgroup takes its next tile slot with one atomic add instead of striding
+  // by gridDim.x: with three batches in flight part of a launch's persistent workgroups find their CU occupied (a recurrence
+  // workgroup of another batch leaves room for one GEMM workgroup, not two) and start late -- with fixed shares the launch
+  // ends when the last of them has worked off its 34 tiles.  The counters are never reset: a launch takes exactly
+  // (slots per XCD + workgroups per XCD) numbers from each, so the host knows where the next launch of that stream starts.
+  unsigned long long* tile_ctr;        // device, [8]; nullptr: static shares
+  unsigned long long tile_base;        // first number of this launch (filled by launch_gemm)
+  unsigned long long* tile_base_host;  // host counter of the owning stream, advanced by launch_gemm
 };
 
 bool launch_gemm(const GemmParams& p, hipStream_t stream);  // false: no kernel for this shape / dtype
