@@ -1152,6 +1152,7 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
           WinoParams wq;
           wq.src = bufA, wq.U = b.wino_u, wq.shift = b.gb.shift, wq.out = bufB;
           wq.B = B, wq.T = b.t_in, wq.C = b.c, wq.N = b.c, wq.lda = b.c, wq.ldo = b.c, wq.relu = 1, wq.f4 = b.wino_f4;
+          wq.tile_ctr = e->dyn_tiles ? s->tile_ctr : nullptr, wq.tile_base = 0, wq.tile_base_host = &s->tile_base;
           // FLOPs of the convolution as the reference defines it (2 * 3 taps * C * C per position); 2/3 of them are executed
           Prof pr(e, s, PN_WINO, 2.0 * B * b.t_out * (double)b.k * b.c * b.c, 4.0 * B * (b.t_in + b.t_out) * b.c);
           done = launch_wino_conv3(wq, s->stream);

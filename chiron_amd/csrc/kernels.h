@@ -122,6 +122,10 @@ struct WinoParams {
   float* out;          // [B*T][ldo]
   int B, T, C, N, lda, ldo, relu;
   int f4;              // 1: F(4,3) (T % 4 == 0), 0: F(2,3) (T % 2 == 0)
+  // dynamic tile numbers of the F(4,3) kernel: as GemmParams::tile_ctr (per-XCD counters of the launching stream)
+  unsigned long long* tile_ctr;
+  unsigned long long tile_base;
+  unsigned long long* tile_base_host;
 };
 bool launch_wino_conv3(const WinoParams& p, hipStream_t stream);  // false: shape not covered
 

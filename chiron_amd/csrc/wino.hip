@@ -356,8 +356,34 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
     fs1[g] = ((2 * g + kh) ^ (((li + 1) >> 2) & 3)) * 4;
   }
 
+  // tile ids: fixed shares (stride gridDim.x) or the next slot of this workgroup's XCD from the stream's counters (see
+  // GemmParams::tile_ctr in kernels.h: a persistent workgroup that starts late no longer sets the end of the launch)
+  __shared__ int sh_next;
+  const bool dyn = p.tile_ctr != nullptr && chunks >= 3;
+  const int my_xcd = blockIdx.x & 7;
+  const unsigned slots_per_xcd = (unsigned)(total_ids >> 3);
+  unsigned long long grabbed = 0;
+  auto issue_grab = [&]() {
+    if (tid == 0) grabbed = atomicAdd(p.tile_ctr + my_xcd, 1ull);
+  };
+  auto decode_grab = [&]() -> int {   // thread 0
+    for (;;) {
+      const unsigned long long v = grabbed - p.tile_base;
+      if (v >= slots_per_xcd) return total_ids;
+      const int id = (int)((unsigned)v << 3) | my_xcd;
+      int mm, nn;
+      if (tile_of(id, mm, nn)) return id;
+      grabbed = atomicAdd(p.tile_ctr + my_xcd, 1ull);
+    }
+  };
   int c_id = blockIdx.x;
-  {
+  if (dyn) {
+    issue_grab();
+    if (tid == 0) sh_next = decode_grab();
+    __syncthreads();
+    c_id = sh_next;
+    if (c_id >= total_ids) return;
+  } else {
     int m0, n0;
     if (c_id >= total_ids) return;
     if (!tile_of(c_id, m0, n0)) c_id = next_valid(c_id);
@@ -404,12 +430,17 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
   while (c_id < total_ids) {
     int m0, n0;
     tile_of(c_id, m0, n0);
-    const int n_id = next_valid(c_id);
+    int n_id = dyn ? total_ids : next_valid(c_id);
     const int qg = m0 + wm * 32 + li;
     const int qq = qg % qpw;
     const bool first = qq == 0, last = qq == qpw - 1;   // SAME padding: x[-1] and x[T] come from the row of zeros
     for (int c = 0; c < chunks; ++c) {
       __syncthreads();   // chunk c has landed in `buf`; buf ^ 1 is free
+      if (dyn) {   // the next tile's number: requested in chunk 0, published in chunk 1, read in chunk 2
+        if (c == 0) issue_grab();
+        if (c == 1 && tid == 0) sh_next = decode_grab();
+        if (c == 2) n_id = sh_next;
+      }
       float* const nxt = lds + (buf ^ 1) * BUF4_F;
       const bool more = c + 1 < chunks;
       const bool go = more || n_id < total_ids;
@@ -485,8 +516,12 @@ bool launch_wino_conv3(const WinoParams& p, hipStream_t stream) {
   static char attr_set[CHIRON_MAX_DEVICES] = {};   // the dynamic-LDS opt-in is a per-device function attribute
   const int dev = current_device_index();
   if (!__atomic_load_n(&attr_set[dev], __ATOMIC_ACQUIRE)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv3_f4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    // what the launches below ask for at most (N <= 1024); the limit counts the kernels' static LDS too, so not "all 160 KB"
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * BUF_F + WK + 1024) * 4) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv3_f4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * BUF4_F + K4 + 1024) * 4) != hipSuccess) {
+      (void)hipGetLastError();   // not sticky: the caller takes the GEMM form
+      return false;
+    }
     __atomic_store_n(&attr_set[dev], (char)1, __ATOMIC_RELEASE);
   }
   int g = (n_cu / 8) * 8;
@@ -495,7 +530,12 @@ bool launch_wino_conv3(const WinoParams& p, hipStream_t stream) {
     const int mblocks = (p.B * (p.T / 4) + Q4 - 1) / Q4;
     const int total_ids = ((mblocks + 7) / 8) * 8 * (p.N / WN);
     if (g > total_ids) g = total_ids;
-    hipLaunchKernelGGL(wino_conv3_f4_kernel, dim3(g), dim3(512), (size_t)(2 * BUF4_F + K4 + p.N) * 4, stream, p);
+    WinoParams q = p;
+    const bool dyn = q.tile_ctr != nullptr && q.tile_base_host != nullptr && p.C / K4 >= 3 && g % 8 == 0;
+    if (dyn) q.tile_base = *q.tile_base_host;
+    else q.tile_ctr = nullptr;
+    hipLaunchKernelGGL(wino_conv3_f4_kernel, dim3(g), dim3(512), (size_t)(2 * BUF4_F + K4 + p.N) * 4, stream, q);
+    if (dyn) *q.tile_base_host += (unsigned long long)(total_ids / 8 + g / 8);   // what the launch takes from each counter
     return true;
   }
   const int half_t = p.T / 2;
