@@ -171,8 +171,10 @@ struct ProfEvent {
 
 struct Slot {
   hipStream_t stream = nullptr;
-  unsigned long long* tile_ctr = nullptr;   // device [8]: per-XCD tile counters of the DMA GEMM (GemmParams::tile_ctr), never reset
-  unsigned long long tile_base = 0;         // host: the number the stream's next GEMM launch starts at
+  unsigned long long* tile_ctr = nullptr;   // device [16]: [0..7] per-XCD tile counters of the DMA GEMM / Winograd kernels (GemmParams::tile_ctr),
+                                            // [8] the streaming 1 x 1 kernel's; never reset
+  unsigned long long tile_base = 0;         // host: the number the stream's next GEMM / Winograd launch starts at
+  unsigned long long tile_base32 = 0;       // host: the same for counter [8]
   float* sig = nullptr;
   int32_t* seq = nullptr;
   float* act[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // 3 in population mode, 5 in batch-BN mode
@@ -767,7 +769,7 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
     cmax = std::max<size_t>(cmax, b.c);
   }
   chiron_status st;
-  if ((st = dev_alloc(e, (void**)&s->tile_ctr, 8 * sizeof(unsigned long long), true))) return st;
+  if ((st = dev_alloc(e, (void**)&s->tile_ctr, 16 * sizeof(unsigned long long), true))) return st;
   if ((st = dev_alloc(e, (void**)&s->sig, B * L * 4, true))) return st;
   if ((st = dev_alloc(e, (void**)&s->seq, BP * 4, true))) return st;
   for (int i = 0; i < (e->bn_batch ? 5 : 3); ++i)
@@ -944,13 +946,16 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
 
 // Segments are filled in ELEMENTS; the f16 kernels address in 4-byte units (see GemmParams::f16).
 static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
-  if (!e->f16 && !e->split && e->stream32 && launch_stream32(g, stream)) return true;   // fp32 256 -> 256 channel 1 x 1 convolutions
+  Slot* own = nullptr;   // the slot this stream belongs to: its tile counters (dynamic tile scheduling)
   if (e->dyn_tiles)
     for (Slot& sl : e->slots)
-      if (sl.stream == stream) {   // the stream's tile counters (dynamic tile scheduling of the DMA GEMM)
-        g.tile_ctr = sl.tile_ctr;
-        g.tile_base_host = &sl.tile_base;
-      }
+      if (sl.stream == stream) own = &sl;
+  if (!e->f16 && !e->split && e->stream32) {   // fp32 256 -> 256 channel 1 x 1 convolutions
+    if (own) g.tile_ctr = own->tile_ctr + 8, g.tile_base_host = &own->tile_base32;
+    if (launch_stream32(g, stream)) return true;
+  }
+  g.tile_ctr = own ? own->tile_ctr : nullptr;
+  g.tile_base_host = own ? &own->tile_base : nullptr;
   if (e->split) g.f16 = 2;  // same 4-byte element units as fp32; only the content of the 128-byte blocks differs
   if (e->f16) {
     if (e->stream16 && launch_stream16(g, stream)) return true;   // 256 -> 256 channel 1 x 1 convolutions: streaming kernel

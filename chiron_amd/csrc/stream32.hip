@@ -73,13 +73,40 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
 
   const int ntiles = (p.M + T_ROWS - 1) / T_ROWS;
   const int first = blockIdx.x, step = gridDim.x;
-  const int mine = first < ntiles ? (ntiles - first + step - 1) / step : 0;
-  if (mine == 0) return;
+  // Tile ids.  Fixed shares: position j of this workgroup is tile first + j * step.  With the stream's counter
+  // (GemmParams::tile_ctr; one counter: rows have no XCD affinity here, the weights sit in registers) every position's tile is
+  // the next number of the counter.  Thread 0 requests the number of position j + 4 at the top of iteration j and publishes it
+  // in an LDS ring at the END of the same iteration -- behind the iteration's DMA and stores, so that the wait the compiler puts
+  // in front of the use is a vmcnt(8) that the request has long satisfied (consumed in the NEXT iteration the value is copied
+  // at the loop's back edge and the wait lands right behind the request: +9 % per launch) -- and everybody reads it after the
+  // next barrier, when the DMA of position j + 4 is due.  A workgroup stops at its first number past the last tile and has
+  // then taken exactly four such numbers: a launch moves the counter by ntiles + 4 * gridDim.x.
+  __shared__ int ring[8];
+  const bool dyn = p.tile_ctr != nullptr;
+  auto take = [&]() -> unsigned long long { return atomicAdd(p.tile_ctr, 1ull); };
+  auto tile_id = [&](unsigned long long v) -> int {
+    const unsigned long long k = v - p.tile_base;
+    return k >= (unsigned long long)ntiles ? ntiles : (int)k;
+  };
+  int cur[4];   // tiles of positions j .. j + 3 (wave-uniform)
+  if (dyn) {
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ring[k] = tile_id(take());
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cur[k] = __builtin_amdgcn_readfirstlane(ring[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cur[k] = first + k * step < ntiles ? first + k * step : ntiles;
+  }
+  if (cur[0] >= ntiles) return;
 
   const __amdgpu_buffer_rsrc_t rs = t_rsrc(p.seg[0].src);
-  auto issue = [&](int j) {   // this wave's 8 of the 64 pieces of tile j (past the last tile: zeros, no memory traffic)
-    const int m = (first + j * step) * T_ROWS + li;
-    const bool ok = j < mine && m < p.M;
+  auto issue = [&](int j, int tile) {   // this wave's 8 of the 64 pieces of position j's tile (past the last tile: zeros, no memory traffic)
+    const int m = tile * T_ROWS + li;
+    const bool ok = tile < ntiles && m < p.M;
     float* base = tiles + (j % T_D) * T_TILE_F;
     const unsigned off = ok ? (unsigned)(((long)m * p.seg[0].lda + p.seg[0].col0) * 4 + kh * 16) : T_OOB;
 #pragma unroll
@@ -99,12 +126,28 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
   const bool relu = p.relu != 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights are in: from here on vmcnt counts tiles and stores only
 #pragma unroll
-  for (int j = 0; j < T_D - 1; ++j) issue(j);
+  for (int j = 0; j < T_D - 1; ++j) issue(j, cur[j]);
 
-  for (int j = 0; j < mine; ++j) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's pieces of tile j have landed
+  for (int j = 0; cur[0] < ntiles; ++j) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's pieces of tile j have landed (thread 0's counter request makes
+                                                        // its wave's wait stricter, never looser)
     tile_barrier();                                     // everybody's have; everybody has finished tile j - 1
-    issue(j + T_D - 1);                                 // ... whose buffer tile j + 3 goes to
+    unsigned long long req;   // (left undefined for the other threads on purpose: an initial value makes the compiler copy the result -- and wait for it -- inside the branch)
+    if (dyn) {
+      // (plain LDS accesses between the barrier's compiler fences: through a volatile pointer they become FLAT instructions, which
+      //  count in vmcnt as well and drag a vmcnt(0) into every wave's iteration)
+      if (j > 0) cur[3] = __builtin_amdgcn_readfirstlane(ring[(j + 3) & 7]);
+      // position j + 4.  Hand-issued: hipcc's atomic optimiser turns a builtin atomic in a divergent branch into one that needs its
+      // result at once (readfirstlane), i.e. an s_waitcnt vmcnt(0) right behind the request, in a wave with three tiles in flight
+      if (tid == 0) {
+        const unsigned zero = 0;
+        const unsigned long long one = 1;
+        asm volatile("global_atomic_add_x2 %0, %1, %2, %3 sc0" : "=v"(req) : "v"(zero), "v"(one), "s"(p.tile_ctr) : "memory");
+      }
+    } else if (j > 0) {
+      cur[3] = first + (j + 3) * step < ntiles ? first + (j + 3) * step : ntiles;
+    }
+    issue(j + T_D - 1, cur[3]);                         // ... whose buffer tile j + 3 goes to
     const float* base = tiles + (j % T_D) * T_TILE_F + (kh * T_ROWS + li) * 4;
     f32x16 acc0, acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -123,7 +166,8 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[g + 1][jj], xb[jj], acc1, 0, 0, 0);
       }
     }
-    const int m = (first + j * step) * T_ROWS + li;
+    const int m = cur[0] * T_ROWS + li;
+    cur[0] = cur[1], cur[1] = cur[2], cur[2] = cur[3];
     if (m < p.M) {
       float* o = outp + (long)m * p.ldo;
       float sv = 0.f;
@@ -145,6 +189,12 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
         }
         *reinterpret_cast<f32x4*>(o + 8 * q) = v;
       }
+    }
+    if (dyn && tid == 0) {
+      // the request is older than this iteration's four DMA instructions (and its stores): at most four operations outstanding
+      // means it has returned (returning operations retire in order)
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(req) : : "memory");
+      ring[(j + 4) & 7] = tile_id(req);
     }
   }
 }
@@ -173,10 +223,15 @@ bool launch_stream32(const GemmParams& p, hipStream_t stream) {
   if (st != 1) return false;
   const int ntiles = (p.M + T_ROWS - 1) / T_ROWS;
   const int grid = std::min(n_cu, ntiles);
+  GemmParams q = p;
+  const bool dyn = q.tile_ctr != nullptr && q.tile_base_host != nullptr;
+  if (dyn) q.tile_base = *q.tile_base_host;
+  else q.tile_ctr = nullptr;
   if (res)
-    hipLaunchKernelGGL(conv1x1_f32_stream_kernel<true>, dim3(grid), dim3(64 * T_NW), lds, stream, p);
+    hipLaunchKernelGGL(conv1x1_f32_stream_kernel<true>, dim3(grid), dim3(64 * T_NW), lds, stream, q);
   else
-    hipLaunchKernelGGL(conv1x1_f32_stream_kernel<false>, dim3(grid), dim3(64 * T_NW), lds, stream, p);
+    hipLaunchKernelGGL(conv1x1_f32_stream_kernel<false>, dim3(grid), dim3(64 * T_NW), lds, stream, q);
+  if (dyn) *q.tile_base_host += (unsigned long long)ntiles + 4ull * (unsigned long long)grid;   // what the launch takes from its counter
   return true;
 }
 
