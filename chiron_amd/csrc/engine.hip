@@ -1351,6 +1351,16 @@ static chiron_status enqueue_decode(chiron_engine* e, Slot* s, int B, int beam_w
   return CHIRON_OK;
 }
 
+// After a failed submit / collect the slot's stream is drained; a launch that never ran has not taken its numbers from the
+// tile counters while the host side already counted them (GemmParams::tile_base), and every later workgroup would read
+// "no tile left".  Both sides restart from zero.
+static void resync_tile_counters(Slot* s) {
+  hipStreamSynchronize(s->stream);
+  if (s->tile_ctr && hipMemsetAsync(s->tile_ctr, 0, 16 * sizeof(unsigned long long), s->stream) == hipSuccess) hipStreamSynchronize(s->stream);
+  s->tile_base = s->tile_base32 = 0;
+  (void)hipGetLastError();
+}
+
 extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, const float* x, const int32_t* seq_len,
                                               int32_t batch, int32_t beam_width, uint32_t flags) {
   if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
@@ -1389,7 +1399,7 @@ extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, co
   };
   const chiron_status st = enqueue();
   if (st) {
-    hipStreamSynchronize(s->stream);
+    resync_tile_counters(s);
     return st;
   }
   s->batch = B;
@@ -1458,7 +1468,7 @@ extern "C" chiron_status chiron_engine_collect(chiron_engine* e, int32_t slot, c
   };
   const chiron_status dst = drain();
   if (dst) {
-    hipStreamSynchronize(s->stream);
+    resync_tile_counters(s);
     s->state.v.store(0, std::memory_order_release);
     return dst;
   }

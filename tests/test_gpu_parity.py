@@ -210,6 +210,47 @@ def test_full_batch_1100_properties(dna):
     assert np.array_equal(r2.logits[same], res.logits[same])
 
 
+def test_tiles_by_counter_equal_fixed_tile_shares(dna, rna, monkeypatch):
+    """The persistent GEMM / Winograd / streaming kernels take their tiles from per-XCD counters of the slot's stream
+    (GemmParams::tile_ctr in kernels.h; CHIRON_STATIC_TILES=1: fixed shares per workgroup).  WHICH workgroup computes a
+    tile must not show in the result: logits and decode are bit-identical between the two schedules, for the full
+    configs[1] batch, a partial batch, the RNA topology (other tile counts, the strided first block) and the fp16 and
+    fp32-split engines -- and stay so while three slots run concurrently for many rounds, i.e. while the counters of a
+    stream keep counting across launches of different kernels and tile counts (the host side only tracks their base)."""
+    cases = [(dna, 400, 390, 1100, "fp32"), (dna, 400, 390, 77, "fp32"), (rna, 500, 490, 400, "fp32"),
+             (dna, 400, 390, 1100, "fp16"), (dna, 400, 390, 300, "fp32-split")]
+    for (spec, w), L, jump, B, dtype in cases:
+        x, ln = _windows(jump * (B - 1) + 111, L, jump, seed=71 + B)
+        ln = ln.copy()
+        ln[[1, B // 2]] = [0, L // 3]
+        perm = np.random.RandomState(5).permutation(B)
+        ref = None
+        for static in (True, False):
+            monkeypatch.delenv("CHIRON_STATIC_TILES", raising=False)
+            if static:
+                monkeypatch.setenv("CHIRON_STATIC_TILES", "1")
+            with ca.Engine(spec, w, max_batch=B, segment_len=L, n_slots=3, dtype=dtype) as eng:
+                sl = ca.seq_len_for_engine(ln, eng.ratio)
+                inputs = [(x, sl), (x[perm], sl[perm]), (x[::-1].copy(), sl[::-1].copy())]
+                first = [eng.infer(xi, si, want_logits=True, slot=k) for k, (xi, si) in enumerate(inputs)]
+                if static:
+                    ref = first
+                else:
+                    for a, b in zip(first, ref):
+                        assert np.array_equal(a.logits.view(np.uint32), b.logits.view(np.uint32)), (dtype, B)
+                        assert np.array_equal(a.decoded.indices, b.decoded.indices) and np.array_equal(a.decoded.values, b.decoded.values)
+                    # counters keep running: 12 rounds with all three slots in flight, slots rotating over the inputs
+                    for r in range(12):
+                        for k in range(3):
+                            xi, si = inputs[(k + r) % 3]
+                            eng.submit(k, xi, si, want_logits=True)
+                        for k in range(3):
+                            got = eng.collect(k)
+                            assert np.array_equal(got.logits.view(np.uint32), ref[(k + r) % 3].logits.view(np.uint32)), (dtype, B, r, k)
+        monkeypatch.delenv("CHIRON_STATIC_TILES", raising=False)
+        assert np.array_equal(ref[1].logits, ref[0].logits[perm])
+
+
 def test_first_conv_table_form_equals_gemm_form(dna, rna, monkeypatch):
     """res_layer1's conv2a + conv2b run as a piecewise-linear table of the signal value (pwl.hip).  CHIRON_NO_PWL=1
     makes the engine materialise conv2a and run conv2b as a GEMM instead: the same function, re-associated -- both
