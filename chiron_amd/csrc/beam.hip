@@ -295,9 +295,15 @@ __global__ __launch_bounds__(64) void beam_kernel(const BeamParams p, int node_c
 // found with one ballot.  Events are applied one at a time with v_readlane / predicated moves, the bottom is
 // a DPP min + ballot.  The result is, by construction, the same sequence of state changes as the literal walk
 // (tests compare the two kernels bit for bit).
-//   node id -> beam slot is a byte table in LDS (1 + beam*T entries), so the per-frame trie look-ups
-//   (is my parent in the beam? which of my children are?) never leave the CU; the trie in HBM is write-mostly
-//   (read back only for a re-inserted node's child ids and for the final back-trace).
+//   Every entry carries the beam SLOT of its parent and of its four children (or "not in the beam") next to their node
+//   ids; the references follow the entries through each frame's re-ranking (old slot -> new rank, a 64-byte table), new
+//   children report their rank to the branch that spawned them, and a node that re-enters the beam finds its relatives by
+//   comparing node ids across the wave (rare).  So "is my parent in the beam? which of my children are?" costs no look-up
+//   at all, and the kernel's LDS is 4.4 KB whatever beam * T is -- it used to keep a node id -> slot byte table of
+//   1 + beam * T entries (12 .. 20 KB), and with the other batches' persistent GEMM workgroups holding 120 .. 133 KB of a
+//   CU's LDS that footprint decided how many windows a CU takes and how long the next GEMM launch waits for its CUs:
+//   measured with three batches in flight, every extra 16 KB per window cost 0.7 ms per 1100-window batch.
+//   The trie in HBM is write-mostly (read back only for a re-inserted node's child ids and for the final back-trace).
 //   Log-softmax of 64 frames at a time is held lane-distributed in registers and broadcast by v_readlane.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -326,10 +332,15 @@ __device__ __forceinline__ void lds_sync() {
 }
 
 __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node_cap) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* scratch = reinterpret_cast<int*>(smem);                  // [B64_FIELDS][64] permutation buffer
-  int* chupd = scratch + B64_FIELDS * 64;                       // [64][4] child ids materialised this frame
-  unsigned char* slot_of = reinterpret_cast<unsigned char*>(chupd + 256);  // [node_cap], 255 = not in the beam
+  __shared__ __attribute__((aligned(16))) int scratch[B64_FIELDS * 64];   // permutation buffer: [field][rank]
+  __shared__ __attribute__((aligned(16))) int chupd[64 * 4];              // [branch slot][label] node id of the child materialised this frame
+  __shared__ unsigned csu[64];          // [branch slot] four bytes: rank + 1 of the child spawned this frame under that label (0: none)
+  __shared__ unsigned csr[64];          // [slot of a re-inserted node] the same for its children that are in the beam
+  __shared__ unsigned char rmap[64];    // old slot -> rank + 1 of the carried entry if it is still a leaf (0: it left the beam)
+  // One latency-bound wave per window next to the other batches' GEMM waves: with equal priority a saturated MFMA wave
+  // leaves a VALU wave of its SIMD about one issue slot per MFMA (tools/ubench/valu_exec_mask.hip).  Measured same-box
+  // with three batches in flight: 11.81 / 11.83 ms per beam-30 batch against 11.87 / 11.95.
+  __builtin_amdgcn_s_setprio(3);
 
   const int W = p.beam;
   const int lane = threadIdx.x;
@@ -343,6 +354,8 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
   float e_tot = 0.f, e_blk = 0.f, e_lab = NEG_INF;
   int e_node = 0, e_par = -1, e_lc = -1, e_depth = 0;
   int e_ch[4] = {-1, -1, -1, -1};
+  int e_ps = -1;                       // beam slot of the parent, -1: not in the beam
+  int e_cs[4] = {-1, -1, -1, -1};      // beam slots of the children, -1: not in the beam (or not in the trie)
   if (lane == 0) {
     BeamNode r;
     r.parent = -1;
@@ -351,9 +364,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
     r.slot = 0;
     r.depth = 0;
     nodes[0] = r;
-    slot_of[0] = 0;
   }
-  __syncthreads();
   int nb = 1;
   int n_nodes = 1;
 
@@ -382,8 +393,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
       {
         const int lc = max(e_lc, 0);
         const float lp_lc = lc == 0 ? logp[0] : lc == 1 ? logp[1] : lc == 2 ? logp[2] : logp[3];
-        int pslot = 255;
-        if (inb && e_par >= 0) pslot = slot_of[e_par];
+        const int pslot = (inb && e_ps >= 0) ? e_ps : 255;
         const int src = pslot & 63;
         const float p_tot = __shfl(e_tot, src), p_blk = __shfl(e_blk, src);
         const int p_lc = __shfl(e_lc, src);
@@ -398,12 +408,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
           l_blk = n_blank;
           l_lab = n_label;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (e_ch[c] >= 0) {
-              const int sl = slot_of[e_ch[c]];
-              chs[c] = sl == 255 ? -1 : sl;
-            }
-          }
+          for (int c = 0; c < 4; ++c) chs[c] = e_cs[c];
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) cand[c] = logp[c] + (c == e_lc ? e_blk : e_tot);
@@ -503,11 +508,13 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
       }
 
       // ---- P3: trie bookkeeping, rank the leaves (descending total), permute into rank order
-      if (inb && l_orig != lane) slot_of[e_node] = 255;   // this lane's carried entry was evicted (its slot holds an inserted child)
       *reinterpret_cast<int4*>(chupd + 4 * lane) = make_int4(-1, -1, -1, -1);
+      csu[lane] = 0u;
+      csr[lane] = 0u;
       const bool isleaf = lane < nL;
-      const bool inserted = isleaf && l_par >= 0;
+      const bool inserted = isleaf && l_par >= 0;     // otherwise a leaf is this lane's carried entry (an evicted one's slot holds an inserted child)
       const bool fresh = inserted && l_node < 0;
+      const bool reins = inserted && !fresh;
       const unsigned long long fm = __ballot(fresh);
       int f_ch[4];
 #pragma unroll
@@ -529,9 +536,10 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
       n_nodes += __popcll(fm);
       // Only a re-inserted node reads the trie back (its children may have been linked by the stores just above), and
       // only then the wave waits for its own global stores.
-      if (__ballot(inserted && !fresh)) __threadfence_block();
+      const unsigned long long reins_m = __ballot(reins);
+      if (reins_m) __threadfence_block();
       lds_sync();
-      if (inserted && !fresh) {
+      if (reins) {
         // a node that was in the beam before (possibly evicted earlier in this very frame, after it had
         // spawned children -- hence after the stores above): its children keep their identity
         const int4 ch = *reinterpret_cast<const int4*>(nodes[l_node].child);
@@ -567,19 +575,53 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
           r += (tk3 > l_tot) || (tk3 == l_tot && k0 + 3 < lane);
         }
       }
+      // Slot references into the next beam (all encoded + 1, 0 = not in the beam).  A carried entry that is still a leaf
+      // publishes its rank under its old slot; whoever referred to that slot follows it, whoever referred to a slot whose
+      // entry left the beam reads 0.  A surviving new child reports its rank to the branch that spawned it.
+      rmap[lane] = (isleaf && !inserted) ? (unsigned char)(r + 1) : (unsigned char)0;
+      if (inserted) reinterpret_cast<unsigned char*>(csu)[4 * l_pi + l_lc] = (unsigned char)(r + 1);
+      lds_sync();
+      unsigned n_ps = 0u, n_cs = 0u;
+      if (isleaf && !inserted) {
+        if (e_ps >= 0) n_ps = rmap[e_ps];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (e_cs[c] >= 0) n_cs |= (unsigned)rmap[e_cs[c]] << (8 * c);
+        const unsigned u = csu[lane];     // a label's old child (if any) has left the beam when a new one could be spawned under it
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (u & (0xFFu << (8 * c))) n_cs = (n_cs & ~(0xFFu << (8 * c))) | (u & (0xFFu << (8 * c)));
+      } else if (inserted) {
+        n_ps = rmap[l_pi];                // the branch that spawned it, if that is still a leaf
+      }
+      // A node that was in the beam before and comes back (possibly within this very frame) may have relatives here that
+      // lost sight of it: every leaf whose parent is that node points to it again, and tells it where it is.
+      if (reins_m) {
+        unsigned long long rm = reins_m;
+        while (rm) {
+          const int i = __builtin_ctzll(rm);
+          rm &= rm - 1ull;
+          const int n = rli(l_node, i), ri = rli(r, i);
+          if (isleaf && f_par == n) {
+            n_ps = (unsigned)(ri + 1);
+            reinterpret_cast<unsigned char*>(csr)[4 * i + l_lc] = (unsigned char)(r + 1);
+          }
+        }
+        lds_sync();
+        if (reins) n_cs = csr[lane];
+      }
       if (isleaf) {
         scratch[0 * 64 + r] = __float_as_int(l_tot);
         scratch[1 * 64 + r] = __float_as_int(l_blk);
         scratch[2 * 64 + r] = __float_as_int(l_lab);
         scratch[3 * 64 + r] = l_node;
         scratch[4 * 64 + r] = f_par;
-        scratch[5 * 64 + r] = l_lc;
-        scratch[6 * 64 + r] = l_depth;
+        scratch[5 * 64 + r] = (l_lc + 1) | (l_depth << 3) | (int)(n_ps << 16);   // label + 1 (3 bits), depth (13 bits: T < 8192 at launch), parent slot + 1
+        scratch[6 * 64 + r] = (int)n_cs;                                          // child slots + 1, one byte per label
         scratch[7 * 64 + r] = f_ch[0];
         scratch[8 * 64 + r] = f_ch[1];
         scratch[9 * 64 + r] = f_ch[2];
         scratch[10 * 64 + r] = f_ch[3];
-        slot_of[l_node] = (unsigned char)r;
       }
       lds_sync();
       nb = nL;
@@ -589,8 +631,13 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         e_lab = __int_as_float(scratch[2 * 64 + lane]);
         e_node = scratch[3 * 64 + lane];
         e_par = scratch[4 * 64 + lane];
-        e_lc = scratch[5 * 64 + lane];
-        e_depth = scratch[6 * 64 + lane];
+        const int pa = scratch[5 * 64 + lane];
+        const unsigned pb = (unsigned)scratch[6 * 64 + lane];
+        e_lc = (pa & 7) - 1;
+        e_depth = (pa >> 3) & 0x1FFF;
+        e_ps = (pa >> 16) - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) e_cs[c] = (int)((pb >> (8 * c)) & 0xFFu) - 1;
         e_ch[0] = scratch[7 * 64 + lane];
         e_ch[1] = scratch[8 * 64 + lane];
         e_ch[2] = scratch[9 * 64 + lane];
@@ -615,10 +662,6 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
   }
 }
 
-static size_t beam64_smem_bytes(int node_cap) {
-  return (size_t)(B64_FIELDS * 64 + 256) * 4 + (((size_t)node_cap + 15) & ~(size_t)15);
-}
-
 static size_t beam_smem_bytes(int W) { return (size_t)W * 4 * (5 + 7 + 8 + 2); }
 
 size_t beam_workspace_bytes(int B, int T, int beam) {
@@ -632,8 +675,8 @@ int launch_beam(const BeamParams& p, hipStream_t stream) {
   // CHIRON_BEAM_GENERIC=1 forces the literal sequential kernel (the tests use it to cross-check the two)
   const char* fg = getenv("CHIRON_BEAM_GENERIC");
   const bool force_generic = fg && fg[0] == '1';
-  if (p.beam <= 64 && beam64_smem_bytes(node_cap) <= 30 * 1024 && !force_generic)
-    hipLaunchKernelGGL(beam64_kernel, dim3(p.B), dim3(64), beam64_smem_bytes(node_cap), stream, p, node_cap);
+  if (p.beam <= 64 && p.T < 8192 && !force_generic)   // T: the depth field of the register kernel's packed entry
+    hipLaunchKernelGGL(beam64_kernel, dim3(p.B), dim3(64), 0, stream, p, node_cap);
   else
     hipLaunchKernelGGL(beam_kernel, dim3(p.B), dim3(64), beam_smem_bytes(p.beam), stream, p, node_cap);
   return 0;

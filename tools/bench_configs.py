@@ -66,6 +66,12 @@ if __name__ == "__main__":
         for B in [int(v) for v in sys.argv[2:]]:
             run("DNA_default seg400 jump390 b%d greedy" % B, ca.dna_default_spec(), 400, 390, B, 0, steps=4)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "slots":  # batches in flight x decoder: `slots 3 4 5` (same-box comparison)
+        for ns in sys.argv[2:]:
+            os.environ["BENCH_SLOTS"] = ns
+            for beam in (30, 0):
+                run("DNA_default seg400 jump390 b1100 beam%d slots%s" % (beam, ns), ca.dna_default_spec(), 400, 390, 1100, beam)
+        sys.exit(0)
     run("RNA_default seg500 jump490 b400 beam50", ca.rna_default_spec(), 500, 490, 400, 50, steps=100)   # 2 ms steps: 100 of them
     run("DNA_default seg400 jump390 b1100 beam30", ca.dna_default_spec(), 400, 390, 1100, 30)
     run("DNA_default seg400 jump390 b1100 beam50", ca.dna_default_spec(), 400, 390, 1100, 50)
