@@ -8,6 +8,8 @@
 //                    (chiron_eval.py:403-409), built on device.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace chiron {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,6 +37,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 template <bool RAW16>
 __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short kernels between the other batches' persistent GEMM waves: see DESIGN 3.2 (small kernels in the mix)
   const int lane = threadIdx.x & 63;
   const int sub = lane >> 4, sl = lane & 15;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -147,17 +150,113 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
   }
 }
 
+// The fp32 / split engines' form: 32 lanes per position, two positions per wave and iteration, lane sl of a half owns the
+// column groups sl and sl + 32.  Half the folded weights per lane: 76 registers instead of 166 -- with three batches in
+// flight the kernel runs in whatever the other batches' persistent GEMM workgroups leave of a SIMD's 512 registers (two
+// GEMM waves: 208), and the number of its waves that fit decides how long a batch waits in it (0.73 ms in the mix for a
+// kernel that takes 0.13 ms alone, profiles/r03_overlap_slots3.txt).
+__device__ __forceinline__ float row32_sum(float v) {   // the sum of a 32-lane half, valid in its upper 16 lanes
+  v = row16_sum(v);
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1, 3
+}
+
+__global__ __launch_bounds__(256) void fc32_kernel(const FcParams p) {
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  const int sub = lane >> 5, sl = lane & 31;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int H = p.H, K = p.K;
+  const int nl = (2 * H) / 4;  // float4 column groups of a row (50 for H=100; <= 64)
+
+  float cw[2][4][CHIRON_KMAX];   // cw[s][j][k] = w[dir][u] * wc[u][k] for column 4*(sl + 32 s) + j
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cidx = 4 * (sl + 32 * s) + j;
+      const bool ok = sl + 32 * s < nl;
+      const int d = ok ? cidx / H : 0;
+      const int u = ok ? cidx - d * H : 0;
+      const float wd = ok ? p.w[d * H + u] : 0.f;
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k) cw[s][j][k] = (ok && k < K) ? wd * p.wc[u * K + k] : 0.f;
+    }
+  float cst = 0.f;               // lane 16 + k of a half: sum_u bias[u]*wc[u][k] + bc[k]
+#pragma unroll
+  for (int k = 0; k < CHIRON_KMAX; ++k) {
+    float s = 0.f;
+    if (k < K) {
+      for (int u = lane; u < H; u += 64) s += p.bias[u] * p.wc[u * K + k];
+    }
+    s = wave_sum(s);
+    if (k < K && sl == 16 + k) cst = s + p.bc[k];
+  }
+
+  const int nb2 = (p.B + 1) >> 1;
+  const int nunits = p.T * nb2;  // (frame, 2-row group)
+  auto load_unit = [&](int q, f32x4 (&h)[2]) {
+    const int t = q / nb2;
+    const int b = (q - t * nb2) * 2 + sub;
+    const long row = (long)t * p.BP + (b < p.B ? b : 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      h[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int f = sl + 32 * s;
+      if (f < nl) {
+        if (p.split) {
+          typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+          const int col = 4 * f;  // 4 consecutive columns never straddle a 32-element block
+          const _Float16* hq = reinterpret_cast<const _Float16*>(p.lasth) + (row * p.ld + (col >> 5) * 32) * 2 + (col & 31);
+          const f16x4 hi = *reinterpret_cast<const f16x4*>(hq), lo = *reinterpret_cast<const f16x4*>(hq + 32);
+          h[s] = (f32x4){(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+        } else {
+          h[s] = *reinterpret_cast<const f32x4*>(p.lasth + row * 2 * H + 4 * f);
+        }
+      }
+    }
+  };
+  f32x4 hn[2];
+  if (wave < nunits) load_unit(wave, hn);
+  for (int q = wave; q < nunits; q += nwaves) {
+    const int t = q / nb2;
+    const int b = (q - t * nb2) * 2 + sub;
+    const bool live = b < p.B;
+    f32x4 h[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) h[s] = hn[s];
+    if (q + nwaves < nunits) load_unit(q + nwaves, hn);  // the next unit's rows are in flight during this one's arithmetic
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < CHIRON_KMAX; ++k) {
+      if (k >= K) break;
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a = fmaf(h[s][j], cw[s][j][k], a);
+      a = row32_sum(a);
+      if (sl == 16 + k) v = a + cst;
+    }
+    if (live && sl >= 16 && sl < 16 + K) p.logits[((long)b * p.T + t) * K + (sl - 16)] = v;
+  }
+}
+
 void launch_fc(const FcParams& p, hipStream_t stream) {
+  static const bool wide16 = getenv("CHIRON_FC16") != nullptr;   // A/B switch: the 16-lane form for every dtype
   if (p.f16 && !p.split)
     hipLaunchKernelGGL(fc_kernel<true>, dim3(256 * 8), dim3(256), 0, stream, p);
-  else
+  else if (wide16)
     hipLaunchKernelGGL(fc_kernel<false>, dim3(256 * 8), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(fc32_kernel, dim3(256 * 16), dim3(256), 0, stream, p);
 }
 
 // --------------------------------------------------------------------------------------------
 // Greedy CTC + path_prob: one wave per segment.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void greedy_kernel(const GreedyParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short kernels between the other batches' persistent GEMM waves: see DESIGN 3.2 (small kernels in the mix)
   const int lane = threadIdx.x & 63;
   const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (b >= p.B) return;
@@ -218,6 +317,7 @@ void launch_greedy(const GreedyParams& p, hipStream_t stream) {
 }
 
 __global__ __launch_bounds__(256) void path_prob_kernel(const PathProbParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short kernels between the other batches' persistent GEMM waves: see DESIGN 3.2 (small kernels in the mix)
   const int lane = threadIdx.x & 63;
   const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (b >= p.B) return;
@@ -248,6 +348,7 @@ void launch_path_prob(const PathProbParams& p, hipStream_t stream) {
 // SparseTensor build: exclusive scan of the per-row counts (one workgroup), then scatter.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void scan_kernel(const SparseParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short kernels between the other batches' persistent GEMM waves: see DESIGN 3.2 (small kernels in the mix)
   __shared__ long part[1024];
   __shared__ int pmax[1024];
   const int tid = threadIdx.x;
@@ -288,6 +389,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const SparseParams p) {
 }
 
 __global__ __launch_bounds__(64) void scatter_kernel(const SparseParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short kernels between the other batches' persistent GEMM waves: see DESIGN 3.2 (small kernels in the mix)
   const int b = blockIdx.x;
   const long off = p.offsets[b];
   const int n = p.count[b];

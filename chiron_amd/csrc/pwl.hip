@@ -23,6 +23,7 @@ constexpr int PWL_MAX_S = 512;    // samples a workgroup looks at: (PWL_TP - 1) 
 
 template <int FMT>
 __global__ __launch_bounds__(256) void pwl_conv_kernel(const PwlConvParams p) {
+  __builtin_amdgcn_s_setprio(3);   // a short kernel between the other batches' persistent GEMM waves
   __shared__ float bps[PWL_MAX_BP];
   __shared__ float refs[PWL_MAX_BP + 1];
   __shared__ float ss[PWL_MAX_S];
