@@ -71,19 +71,19 @@ def make_batches(n_batches, rank):
 
 
 # profiling bucket of the engine (chiron_engine_profile) -> kernel symbol(s) in a rocprofv3 trace; template arguments of
-# gemm_f32_dma_kernel are <ZOUT, RES, chunks per K-segment, K tail, mode (0 fp32, 1 f16, 2 split)>
+# gemm_f32_dma_kernel are <ZOUT, RES, chunks per K-segment, K tail, mode (0 fp32, 1 f16, 2 split), single K-segment>
 _REC_FORM = os.environ.get("CHIRON_LSTM_WIDE", "2")     # engine.hip CHIRON_LSTM_WIDE_DEFAULT
 _STREAM32 = os.environ.get("CHIRON_NO_STREAM32") is None
 BUCKET_SYMBOL = {
     # the recurrence: lstm32w2_kernel = 16 rows per workgroup on v_mfma_f32_16x16x4_f32, ONE workgroup per 16-row group and
     # direction (138 for batch 1100: 54 % of the CUs); lstm_kernel<1> = the 4-row form (CHIRON_LSTM_WIDE=0)
     "lstm_recurrence": {"0": "lstm_kernel<1>", "1": "lstm32w_kernel", "2": "lstm32w2_kernel"}.get(_REC_FORM, "lstm32w2_kernel"),
-    "conv_dma": "gemm_f32_dma_kernel<false, false, 8, false, 0>",          # conv2c+branch1 (K=512) of res_layer2/3 (and conv2a with CHIRON_NO_STREAM32)
-    "conv2a": "conv1x1_f32_stream_kernel<false>" if _STREAM32 else "gemm_f32_dma_kernel<false, false, 8, false, 0>",   # conv2a (K=256) of res_layer2/3
+    "conv_dma": "gemm_f32_dma_kernel<false, false, 8, false, 0, false>",          # conv2c+branch1 (K=512) of res_layer2/3 (and conv2a with CHIRON_NO_STREAM32)
+    "conv2a": "conv1x1_f32_stream_kernel<false>" if _STREAM32 else "gemm_f32_dma_kernel<false, false, 8, false, 0, false>",   # conv2a (K=256) of res_layer2/3
     "conv_wino": "wino_conv3_f4_kernel",                                    # conv2b of res_layer2/3, Winograd F(4,3) (T % 4 == 0)
-    "conv_res": "conv1x1_f32_stream_kernel<true>" if _STREAM32 else "gemm_f32_dma_kernel<false, true, 8, false, 0>",   # conv2c + signal branch of res_layer1
-    "lstm_proj0_dma": "gemm_f32_dma_kernel<true, false, 8, false, 0>",      # x-projection of layer 0 (K = 256)
-    "lstm_proj_dma": "gemm_f32_dma_kernel<true, false, 7, true, 0>",        # x-projections of layers 1, 2 (K = 200)
+    "conv_res": "conv1x1_f32_stream_kernel<true>" if _STREAM32 else "gemm_f32_dma_kernel<false, true, 8, false, 0, false>",   # conv2c + signal branch of res_layer1
+    "lstm_proj0_dma": "gemm_f32_dma_kernel<true, false, 8, false, 0, true>",      # x-projection of layer 0 (K = 256)
+    "lstm_proj_dma": "gemm_f32_dma_kernel<true, false, 7, true, 0, true>",        # x-projections of layers 1, 2 (K = 200)
 }
 
 

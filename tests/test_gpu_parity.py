@@ -799,6 +799,28 @@ def test_decode_only_entry_brute_force_and_random(dna):
             _check_beam(r, lg, sl2, beam, B)
 
 
+def test_decoded_sparse_tensor_of_a_quarter_million_entries(dna):
+    """The SparseTensor's size is only known on the device: collect reads nnz, then fetches that many entries.  Random
+    logits make the greedy decoder emit on 0.64 of the frames -- 1100 x 400 -> ~280 k entries (the bench batch decodes to
+    6 k) -- then a short batch and the long one again on the same slot: each equals the oracle's SparseTensor entry for
+    entry (no stale tail, no truncation)."""
+    spec, w = dna
+    rng = np.random.RandomState(17)
+    B = 1100
+    lg = (rng.randn(B, 400, 5) * 2.0).astype(np.float32)
+    with ca.Engine(spec, w, max_batch=B, segment_len=400) as eng:
+        sl = np.full(B, 400, np.int32)
+        big = eng.decode(lg, sl, beam_width=0)
+        assert big.decoded.values.shape[0] > 256 * 1024
+        _check_decode(big, lg, sl, B)
+        sl_small = rng.randint(0, 120, size=B).astype(np.int32)      # ~ 40 k entries
+        small = eng.decode(lg, sl_small, beam_width=0)
+        assert 0 < small.decoded.values.shape[0] < 128 * 1024
+        _check_decode(small, lg, sl_small, B)
+        big2 = eng.decode(lg, sl, beam_width=0)
+        assert np.array_equal(big2.decoded.indices, big.decoded.indices) and np.array_equal(big2.decoded.values, big.decoded.values)
+
+
 def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
     """beam <= 64 runs the event-driven in-register kernel (beam.hip beam64_kernel); CHIRON_BEAM_GENERIC=1
     forces the literal sequential walk.  Both restate the same TF Step() order, so they must agree bit for
