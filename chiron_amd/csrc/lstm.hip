@@ -1089,6 +1089,18 @@ constexpr int W32_PK = 8;   // k-steps of tile 24 per partial wave (waves 0, 1, 
 //   * tile 24's partial products sit under a wave-uniform branch per 8-k-step chunk, not per k-step.
 #define W32_ZLOAD(dst, vo, off) asm volatile("global_load_dword %0, %1, %2 offset:" #off : "=v"(dst) : "v"(vo), "s"(zs) : "memory")
 
+#ifndef CHIRON_SENS
+#define CHIRON_SENS 0
+#endif
+__device__ __forceinline__ float sens_cell(f32x4 q, float c, float* h_out) {
+#if CHIRON_SENS & 1
+  const float cn = 0.25f * (q[0] + q[1]) + 0.5f * c;
+  *h_out = 0.25f * (q[2] + q[3]) + 0.1f * cn;
+  return cn;
+#else
+  return lstm_cell(q, c, h_out);
+#endif
+}
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmParams p) {
   __shared__ __attribute__((aligned(16))) float hbuf[2 * HW32];
   __shared__ __attribute__((aligned(16))) float part[4 * 256];    // [partial wave 0..2 | wave 7's own last-k-step product + z][lane][4 gates]
@@ -1162,7 +1174,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
     f32x4 sum = pp[0] + pp[64];
     sum = sum + pp[128];
     float hnew;
-    c24 = lstm_cell(sum + pp[192], c24, &hnew);   // pp[192]: wave 7's own last-k-step product + z (kept in the LDS, not in registers)
+    c24 = sens_cell(sum + pp[192], c24, &hnew);   // pp[192]: wave 7's own last-k-step product + z (kept in the LDS, not in registers)
     hbuf[buf * HW32 + 24 * 64 + lane] = hnew;
   };
 
@@ -1202,7 +1214,12 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][8 * ch + j], hv[ch & 1][j], (ch == 0 && j == 0) ? zero4 : acc[n], 0, 0, 0);
+          for (int n = 0; n < 3; ++n) {
+#if CHIRON_SENS & 8
+            if (j & 1) { acc[n][0] += w[n][8 * ch + j] * hv[ch & 1][j]; continue; }   // timing experiment: half of the MFMAs
+#endif
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][8 * ch + j], hv[ch & 1][j], (ch == 0 && j == 0) ? zero4 : acc[n], 0, 0, 0);
+          }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1222,7 +1239,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w2_kernel(const LstmPara
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       float hnew;
-      c[n] = lstm_cell(acc[n] + z4[n], c[n], &hnew);
+      c[n] = sens_cell(acc[n] + z4[n], c[n], &hnew);
       hbuf[(cur ^ 1) * HW32 + (tile0 + n) * 64 + lane] = hnew;
     }
     cur ^= 1;

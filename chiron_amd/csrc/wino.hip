@@ -410,10 +410,14 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
         const int e = 4 * q + r;
         const float m0_ = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
         const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+#if defined(CHIRON_SENS) && (CHIRON_SENS & 4)
+        y0[r] = m0_ + m4, y1[r] = m1, y2[r] = m2 + m5, y3[r] = m3 + s4[r];   // timing experiment: no output transform
+#else
         y0[r] = ((m0_ + s12) + s34) + s4[r];
         y1[r] = fmaf(2.0f, d34, d12) + s4[r];
         y2[r] = fmaf(4.0f, s34, s12) + s4[r];
         y3[r] = (fmaf(8.0f, d34, d12) + m5) + s4[r];
+#endif
         if (p.relu) {
           y0[r] = __builtin_amdgcn_fmed3f(y0[r], 0.f, INFINITY);
           y1[r] = __builtin_amdgcn_fmed3f(y1[r], 0.f, INFINITY);
@@ -492,6 +496,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
           v[4][2 * h] = w4[0], v[4][2 * h + 1] = w4[1];
           v[5][2 * h] = w5[0], v[5][2 * h + 1] = w5[1];
         }
+#if defined(CHIRON_SENS) && (CHIRON_SENS & 2)
+        v[0] = d0, v[1] = d1, v[2] = d2, v[3] = d3, v[4] = d4, v[5] = d5;   // timing experiment: no input transform
+#endif
         if (go) issue_part(g, nc, nxt);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
