@@ -824,6 +824,50 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int n = 0; n < W16_NT; ++n) acc[g][n] = n < nt ? biasl[4 * n] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#if CHIRON_F16F_VARIANT == 0
+    // One branch-free sequence of KSX + 4 k-steps for the three tile slots every wave has, the B fragments of k-step k + 1 read
+    // before the MFMAs of k-step k are issued (with the fourth slot tested inside the loop every k-step ended in a branch, and
+    // the compiler put each k-step's tile reads, their wait and its MFMAs strictly behind one another); wave 7's fourth tile
+    // follows on its own and reads the fragments again.
+    {
+      auto frag = [&](int k, int g) -> f16x8 {   // k < KSX: x tile, else h tile
+        return k < KSX ? reinterpret_cast<const f16x8*>(xbuf + (xcur * NG + g) * XQ * 128)[k * 64 + lane]
+                       : reinterpret_cast<const f16x8*>(hbuf + (cur * NG + g) * HF16)[(k - KSX) * 64 + lane];
+      };
+      f16x8 fb[2][NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) fb[0][g] = frag(0, g);
+#pragma unroll
+      for (int k = 0; k < KSX + F16_KS; ++k) {
+        if (k + 1 < KSX + F16_KS) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g) fb[(k + 1) & 1][g] = frag(k + 1, g);
+        }
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          const f16x8 wv = k < KSX ? wx[n][k < KSX ? k : 0] : wh[n][k < KSX ? 0 : k - KSX];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, fb[k & 1][g], acc[g][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one k-step of look-ahead, not eleven (the kernel sits at 246 registers)
+      }
+      if (nt == 4) {   // wave-uniform
+#pragma unroll
+        for (int k = 0; k < KSX + F16_KS; ++k) {
+          f16x8 wv;
+          if (k < KSX) {
+            if (3 < NTR) wv = wx[3 < NTR ? 3 : 0][k < KSX ? k : 0];
+            else wv = reinterpret_cast<const f16x8*>(wx3)[(k < KSX ? k : 0) * 64 + lane];
+          } else {
+            wv = wh[3][k < KSX ? 0 : k - KSX];
+          }
+#pragma unroll
+          for (int g = 0; g < NG; ++g) acc[g][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, frag(k, g), acc[g][3], 0, 0, 0);
+          if (k & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < KSX; ++ks) {
       f16x8 xa[NG];
@@ -871,6 +915,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
 #endif
         }
     }
+#endif
     // the pieces of step s + 1 (issued during step s - 1) have landed when at most this step's NG instructions are
     // outstanding.  The wait sits HERE, behind the products and before this step's output stores: vmcnt counts loads and stores
     // together, and behind the stores (round 2) it made every step wait for its own stores' write acknowledgements.
