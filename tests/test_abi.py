@@ -146,3 +146,21 @@ def test_engine_plan_sizes_and_addressing_limits(built):
     blob = np.zeros(sum(int(np.prod(v)) for v in dna.variables().values()), np.float32)
     h = C.c_void_p()
     assert lib.chiron_engine_create(C.byref(d), blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(o), C.byref(h)) == _lib.ERR_OVERFLOW
+
+
+def test_every_environment_switch_of_the_product_is_documented():
+    """The engine's A/B and debugging switches are read with getenv("CHIRON_...") in csrc/ and os.environ in the Python
+    host side; INTEGRATION.md's table is what a maintainer sees.  A switch missing from it fails here."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for path in glob.glob(os.path.join(root, "chiron_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "chiron_amd", "csrc", "*.cpp")):
+        found.update(re.findall(r'getenv\("(CHIRON_[A-Z0-9_]+)"\)', open(path).read()))
+    for path in glob.glob(os.path.join(root, "chiron_amd", "*.py")):
+        found.update(re.findall(r'environ(?:\.get)?[\(\[]\s*"(CHIRON_[A-Z0-9_]+)"', open(path).read()))
+    assert len(found) > 10            # the scan itself works
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(e for e in found if e not in doc)
+    assert not missing, "environment switches not in INTEGRATION.md: %s" % missing
