@@ -173,3 +173,41 @@ def test_device_header_restates_the_same_operations(tmp_path):
         lib.h_lsm(x.ctypes.data, o.ctypes.data)
         _, lp = c_oracle.beam(x.reshape(1, 1, 5), [1], 1)
         assert f32(lp[0, 0]) == f32(o.max())
+
+
+def test_beam_scores_against_torch_ctc_forward_algorithm(built):
+    """An implementation nobody here wrote: torch.nn.functional.ctc_loss computes -log p(labelling | x) exactly with the CTC
+    forward algorithm.  A prefix beam search returns, for its top labelling, the log of the probability mass of that
+    labelling's alignments that SURVIVED in the beam -- never more than the exact value, and exactly the exact value while
+    no prefix has been pruned (T = 3: 85 prefixes, beam 256).  Checked for the C oracle (float32, the device's bit-exact
+    partner) and the float64 Python oracle, on flat and blank-dominated posteriors, ragged lengths, widths 5 .. 256."""
+    import torch
+    from oracle import c_oracle, ctc_oracle
+
+    def exact_log_prob(lg, sl, rows):
+        B, T, K = lg.shape
+        lp = torch.log_softmax(torch.from_numpy(lg.astype(np.float64)), dim=2).permute(1, 0, 2)
+        tl = torch.tensor([len(r) for r in rows])
+        tg = torch.tensor([v for r in rows for v in r], dtype=torch.long)
+        loss = torch.nn.functional.ctc_loss(lp, tg, torch.from_numpy(sl.astype(np.int64)), tl, blank=K - 1, reduction="none")
+        return -loss.numpy()
+
+    rng = np.random.RandomState(3)
+    for scale, bias in ((0.7, 0.0), (4.0, 3.0)):
+        for T, W in ((3, 256), (10, 256), (60, 30), (400, 30), (400, 5)):
+            B = 12
+            lg = (rng.randn(B, T, 5) * scale).astype(np.float32)
+            lg[..., 4] += bias
+            sl = rng.randint(1, T + 1, size=B).astype(np.int32)
+            sl[0] = T
+            rows, lp = c_oracle.beam(lg, sl, W)
+            ex = exact_log_prob(lg, sl, rows)
+            assert (lp[:, 0] <= ex + 2e-5 * np.maximum(1.0, np.abs(ex))).all(), (T, W, scale)
+            if T == 3:
+                assert np.abs(lp[:, 0] - ex).max() < 1e-5
+            if T <= 60:   # the float64 Python restatement (slow): the same bound, tighter tolerance
+                prow, plp = ctc_oracle.beam_search_decode(lg, sl, W)
+                pex = exact_log_prob(lg, sl, prow)
+                assert (plp[:, 0] <= pex + 1e-9).all()
+                if T == 3:
+                    assert np.abs(plp[:, 0] - pex).max() < 1e-9
