@@ -662,6 +662,351 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// beam <= 32: TWO windows per wave (lanes 0..31 / 32..63, lane & 31 = beam slot).
+//
+// The hardware does not skip the empty 16-lane passes of a partly masked wave (tools/ubench/valu_exec_mask.hip), so a
+// 30-wide beam in a 64-wide wave pays for the idle half -- and next to the other batches' GEMM waves what the decoder costs
+// is its issue slots.  Here the lane-parallel phases (P1, P3) serve both windows with the same instructions; the event
+// walk (P2) advances both windows in lockstep, one event of each per iteration, with everything that was wave-uniform in
+// beam64_kernel (counts, the top-N bottom, the event's branch and label) uniform per HALF instead: held in VGPRs, broadcast
+// inside a half through the LDS crossbar (ds_bpermute) instead of v_readlane.  Same sequence of state changes per window,
+// so the same results bit for bit (tests compare the two kernels and the oracle).  A window that is shorter than its
+// neighbour idles through the extra frames with its entries carried unchanged (re-ranking equal totals is the identity).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_min(float v) {   // minimum over the 32 lanes of this lane's half, in every lane
+  v = fminf(v, dpp_f<0xB1>(v));
+  v = fminf(v, dpp_f<0x4E>(v));
+  v = fminf(v, dpp_f<0x141>(v));
+  v = fminf(v, dpp_f<0x140>(v));
+  return fminf(v, __shfl_xor(v, 16));
+}
+
+__global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int node_cap) {
+  __shared__ __attribute__((aligned(16))) int scratch[B64_FIELDS * 64];
+  __shared__ __attribute__((aligned(16))) int chupd[64 * 4];
+  __shared__ unsigned csu[64];
+  __shared__ unsigned csr[64];
+  __shared__ unsigned char rmap[64];
+  __builtin_amdgcn_s_setprio(3);
+
+  const int W = p.beam;
+  const int lane = threadIdx.x;
+  const int hl = lane & 31, hb = lane & 32;
+  const bool h = lane >= 32;
+  const int b = 2 * blockIdx.x + (h ? 1 : 0);
+  const bool valid = b < p.B;                      // odd batch: the last wave's upper half has no window
+  const int bc = valid ? b : p.B - 1;
+  const int K = p.K, T = p.T;
+  const int len = valid ? min(max(p.seq_len[bc], 0), T) : 0;
+  const int lenmax = max(rli(len, 0), rli(len, 32));
+  BeamNode* nodes = reinterpret_cast<BeamNode*>(p.workspace) + (long)bc * node_cap;
+  const float* lg = p.logits + (long)bc * T * K;
+  auto pick = [&](unsigned lo, unsigned hi) -> unsigned { return h ? hi : lo; };   // a per-half scalar into the lanes of its half
+
+  float e_tot = 0.f, e_blk = 0.f, e_lab = NEG_INF;
+  int e_node = 0, e_par = -1, e_lc = -1, e_depth = 0;
+  int e_ch[4] = {-1, -1, -1, -1};
+  int e_ps = -1;
+  int e_cs[4] = {-1, -1, -1, -1};
+  if (hl == 0 && valid) {
+    BeamNode r;
+    r.parent = -1;
+    r.label = -1;
+    r.child[0] = r.child[1] = r.child[2] = r.child[3] = -1;
+    r.slot = 0;
+    r.depth = 0;
+    nodes[0] = r;
+  }
+  int nb = 1;        // per half
+  int n_nodes = 1;   // per half
+
+  for (int t0 = 0; t0 < lenmax; t0 += 32) {
+    float lpk[CHIRON_KMAX];
+    {
+      const int t = max(min(t0 + hl, len - 1), 0);
+      float x[CHIRON_KMAX];
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k) x[k] = lg[t * K + k];
+      ctc_log_softmax<CHIRON_KMAX>(x, lpk);
+    }
+    const int tn = min(32, lenmax - t0);
+    for (int tt = 0; tt < tn; ++tt) {
+      const bool live = t0 + tt < len;
+      float logp[CHIRON_KMAX];
+#pragma unroll
+      for (int k = 0; k < CHIRON_KMAX; ++k) logp[k] = __shfl(lpk[k], hb + tt);
+      const float lp_blank = logp[CHIRON_KMAX - 1];
+
+      // ---- P1
+      const bool have = hl < nb;
+      const bool inb = live && have;
+      float l_tot = INFINITY, l_blk = NEG_INF, l_lab = NEG_INF;
+      int chs[4] = {-1, -1, -1, -1};
+      float cand[4];
+      {
+        const int lc = max(e_lc, 0);
+        const float lp_lc = lc == 0 ? logp[0] : lc == 1 ? logp[1] : lc == 2 ? logp[2] : logp[3];
+        const int pslot = (inb && e_ps >= 0) ? e_ps : 255;
+        const int src = hb + (pslot & 31);
+        const float p_tot = __shfl(e_tot, src), p_blk = __shfl(e_blk, src);
+        const int p_lc = __shfl(e_lc, src);
+        float n_label = e_lab;
+        if (e_par >= 0) {
+          if (pslot != 255) n_label = log_sum_exp(n_label, (e_lc == p_lc) ? p_blk : p_tot);
+          n_label += lp_lc;
+        }
+        const float n_blank = e_tot + lp_blank;
+        if (inb) {
+          l_tot = log_sum_exp(n_blank, n_label);
+          l_blk = n_blank;
+          l_lab = n_label;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) chs[c] = e_cs[c];
+        } else if (have) {   // a window past its end: the entry is carried as it is
+          l_tot = e_tot;
+          l_blk = e_blk;
+          l_lab = e_lab;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cand[c] = logp[c] + (c == e_lc ? e_blk : e_tot);
+      }
+      int l_node = e_node, l_par = -1, l_lc = e_lc, l_depth = e_depth, l_orig = inb ? hl : -1, l_pi = -1;
+
+      // ---- P2 (see beam64_kernel): nL, full, botv, boti are uniform per half
+      int nL = nb;
+      float botv = NEG_INF;
+      int boti = 0;
+      bool full = nL >= W;
+      auto bottom = [&](bool want) {   // the halves that `want` take their new bottom
+        const float v = half_min(hl < nL ? l_tot : INFINITY);
+        const unsigned long long m = __ballot(hl < nL && l_tot == v);
+        const int bi = __builtin_ctz(pick((unsigned)m, (unsigned)(m >> 32)) | 0x80000000u);
+        if (want) {
+          botv = v;
+          boti = bi;
+        }
+      };
+      if (__ballot(full)) bottom(full);
+      const bool has_old = inb && e_tot > NEG_INF;
+      unsigned pend = has_old ? 0xFu : 0u, act = 0u, cdead = 0u, cfin = 0u, cafter = 0u;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (chs[c] >= 0) act |= 1u << c;
+        if (cand[c] > NEG_INF) cfin |= 1u << c;
+        if (chs[c] > hl) cafter |= 1u << c;
+      }
+      bool passed = false, dead = false;
+      while (true) {
+        const bool br = passed || (!dead && (!full || e_tot > botv));
+        unsigned cnd = cfin;
+        if (full) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (!(cand[c] > botv)) cnd &= ~(1u << c);
+        }
+        const unsigned rst = ~cnd & cafter & ~cdead;
+        const unsigned ev = br ? (pend & ~act & (cnd | rst)) : 0u;
+        const unsigned long long evm = __ballot(ev != 0u);
+        if (evm == 0ull) break;
+        const unsigned evh = pick((unsigned)evm, (unsigned)(evm >> 32));
+        const bool hev = evh != 0u;                                  // this half has an event in this iteration
+        const int i = __builtin_ctz(evh | 0x80000000u);              // its branch (slot in the half)
+        const int src = hb + i;
+        const int c = __shfl(__builtin_ctz(ev | 16u), src) & 3;
+        const bool ins = hev && ((__shfl((int)cnd, src) >> c) & 1);
+        const bool rs = hev && !ins;
+        const float sel_tot = c == 0 ? cand[0] : c == 1 ? cand[1] : c == 2 ? cand[2] : cand[3];
+        const int sel_node = c == 0 ? e_ch[0] : c == 1 ? e_ch[1] : c == 2 ? e_ch[2] : e_ch[3];
+        const int sel_co = c == 0 ? chs[0] : c == 1 ? chs[1] : c == 2 ? chs[2] : chs[3];
+        const float tot = __shfl(sel_tot, src);
+        const int node = __shfl(sel_node, src);
+        const int pnode = __shfl(e_node, src);
+        const int depth = __shfl(e_depth, src) + 1;
+        const int co = __shfl(sel_co, src);
+        // insertion: the bottom leaves the search (full) or the leaves grow by one
+        const int slot = full ? boti : nL;
+        const int jo = __shfl(l_orig, hb + (slot & 31));
+        if (ins && full && jo >= 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (chs[k] == jo) act &= ~(1u << k);
+        }
+        if (ins && !full) nL += 1;
+        if (ins && hl == slot) {
+          l_tot = tot;
+          l_blk = NEG_INF;
+          l_lab = tot;
+          l_node = node;
+          l_par = pnode;
+          l_lc = c;
+          l_depth = depth;
+          l_orig = -1;
+          l_pi = i;
+        }
+        if (ins) full = nL >= W;
+        if (__ballot(ins && full)) bottom(ins && full);
+        // rejection of a child that is a branch still waiting: TF resets its old probability
+        if (rs) {
+          if (hl == co) dead = true;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (chs[k] == co) cdead |= 1u << k;
+        }
+        // the walk is now past (i, c)
+        if (hev) {
+          if (hl < i) pend = 0u;
+          if (hl == i) {
+            pend &= ~((2u << c) - 1u);
+            passed = true;
+          }
+        }
+      }
+
+      // ---- P3
+      *reinterpret_cast<int4*>(chupd + 4 * lane) = make_int4(-1, -1, -1, -1);
+      csu[lane] = 0u;
+      csr[lane] = 0u;
+      const bool isleaf = hl < nL;
+      const bool inserted = isleaf && l_par >= 0;
+      const bool fresh = inserted && l_node < 0;
+      const bool reins = inserted && !fresh;
+      const unsigned long long fm = __ballot(fresh);
+      const unsigned fmh = pick((unsigned)fm, (unsigned)(fm >> 32));
+      int f_ch[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) f_ch[c] = e_ch[c];
+      int f_par = e_par;
+      if (inserted) f_par = l_par;
+      if (fresh) {
+        l_node = n_nodes + __popc(fmh & ((1u << hl) - 1u));
+        BeamNode nd;
+        nd.parent = l_par;
+        nd.label = l_lc;
+        nd.child[0] = nd.child[1] = nd.child[2] = nd.child[3] = -1;
+        nd.slot = 0;
+        nd.depth = l_depth;
+        nodes[l_node] = nd;
+        nodes[l_par].child[l_lc] = l_node;
+        f_ch[0] = f_ch[1] = f_ch[2] = f_ch[3] = -1;
+      }
+      n_nodes += __popc(fmh);
+      const unsigned long long reins_m = __ballot(reins);
+      if (reins_m) __threadfence_block();
+      lds_sync();
+      if (reins) {
+        const int4 ch = *reinterpret_cast<const int4*>(nodes[l_node].child);
+        f_ch[0] = ch.x;
+        f_ch[1] = ch.y;
+        f_ch[2] = ch.z;
+        f_ch[3] = ch.w;
+      }
+      if (inserted) chupd[4 * (hb + l_pi) + l_lc] = l_node;
+      lds_sync();
+      if (isleaf && !inserted) {
+        const int4 u = *reinterpret_cast<const int4*>(chupd + 4 * lane);
+        f_ch[0] = u.x >= 0 ? u.x : f_ch[0];
+        f_ch[1] = u.y >= 0 ? u.y : f_ch[1];
+        f_ch[2] = u.z >= 0 ? u.z : f_ch[2];
+        f_ch[3] = u.w >= 0 ? u.w : f_ch[3];
+      }
+      scratch[lane] = __float_as_int(isleaf ? l_tot : NEG_INF);
+      lds_sync();
+      int r = 0;
+      {
+        const int nq = (max(rli(nL, 0), rli(nL, 32)) + 3) >> 2;   // wave-uniform; a half's entries past its own leaves hold -inf
+        for (int q4 = 0; q4 < nq; ++q4) {
+          const int4 t4 = *reinterpret_cast<const int4*>(scratch + hb + 4 * q4);
+          const float tk0 = __int_as_float(t4.x), tk1 = __int_as_float(t4.y), tk2 = __int_as_float(t4.z), tk3 = __int_as_float(t4.w);
+          const int k0 = 4 * q4;
+          r += (tk0 > l_tot) || (tk0 == l_tot && k0 < hl);
+          r += (tk1 > l_tot) || (tk1 == l_tot && k0 + 1 < hl);
+          r += (tk2 > l_tot) || (tk2 == l_tot && k0 + 2 < hl);
+          r += (tk3 > l_tot) || (tk3 == l_tot && k0 + 3 < hl);
+        }
+      }
+      rmap[lane] = (isleaf && !inserted) ? (unsigned char)(r + 1) : (unsigned char)0;
+      if (inserted) reinterpret_cast<unsigned char*>(csu)[4 * (hb + l_pi) + l_lc] = (unsigned char)(r + 1);
+      lds_sync();
+      unsigned n_ps = 0u, n_cs = 0u;
+      if (isleaf && !inserted) {
+        if (e_ps >= 0) n_ps = rmap[hb + e_ps];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (e_cs[c] >= 0) n_cs |= (unsigned)rmap[hb + e_cs[c]] << (8 * c);
+        const unsigned u = csu[lane];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (u & (0xFFu << (8 * c))) n_cs = (n_cs & ~(0xFFu << (8 * c))) | (u & (0xFFu << (8 * c)));
+      } else if (inserted) {
+        n_ps = rmap[hb + l_pi];
+      }
+      if (reins_m) {
+        unsigned long long rm = reins_m;
+        while (rm) {
+          const int i = __builtin_ctzll(rm);   // a lane of the wave: only its own half can hold its relatives
+          rm &= rm - 1ull;
+          const int n = rli(l_node, i), ri = rli(r, i);
+          if ((lane >> 5) == (i >> 5) && isleaf && f_par == n) {
+            n_ps = (unsigned)(ri + 1);
+            reinterpret_cast<unsigned char*>(csr)[4 * i + l_lc] = (unsigned char)(r + 1);
+          }
+        }
+        lds_sync();
+        if (reins) n_cs = csr[lane];
+      }
+      if (isleaf) {
+        const int o = hb + r;
+        scratch[0 * 64 + o] = __float_as_int(l_tot);
+        scratch[1 * 64 + o] = __float_as_int(l_blk);
+        scratch[2 * 64 + o] = __float_as_int(l_lab);
+        scratch[3 * 64 + o] = l_node;
+        scratch[4 * 64 + o] = f_par;
+        scratch[5 * 64 + o] = (l_lc + 1) | (l_depth << 3) | (int)(n_ps << 16);
+        scratch[6 * 64 + o] = (int)n_cs;
+        scratch[7 * 64 + o] = f_ch[0];
+        scratch[8 * 64 + o] = f_ch[1];
+        scratch[9 * 64 + o] = f_ch[2];
+        scratch[10 * 64 + o] = f_ch[3];
+      }
+      lds_sync();
+      nb = nL;
+      if (hl < nb) {
+        e_tot = __int_as_float(scratch[0 * 64 + lane]);
+        e_blk = __int_as_float(scratch[1 * 64 + lane]);
+        e_lab = __int_as_float(scratch[2 * 64 + lane]);
+        e_node = scratch[3 * 64 + lane];
+        e_par = scratch[4 * 64 + lane];
+        const int pa = scratch[5 * 64 + lane];
+        const unsigned pb = (unsigned)scratch[6 * 64 + lane];
+        e_lc = (pa & 7) - 1;
+        e_depth = (pa >> 3) & 0x1FFF;
+        e_ps = (pa >> 16) - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) e_cs[c] = (int)((pb >> (8 * c)) & 0xFFu) - 1;
+        e_ch[0] = scratch[7 * 64 + lane];
+        e_ch[1] = scratch[8 * 64 + lane];
+        e_ch[2] = scratch[9 * 64 + lane];
+        e_ch[3] = scratch[10 * 64 + lane];
+      }
+      lds_sync();
+    }
+  }
+
+  __threadfence_block();
+  if (hl == 0 && valid) {
+    int n = e_node;
+    uint8_t* out = p.labels + (long)b * T;
+    p.count[b] = e_depth;
+    p.log_prob[b] = e_tot;
+    while (n > 0) {
+      const BeamNode nd = nodes[n];
+      out[nd.depth - 1] = (uint8_t)nd.label;
+      n = nd.parent;
+    }
+  }
+}
+
 static size_t beam_smem_bytes(int W) { return (size_t)W * 4 * (5 + 7 + 8 + 2); }
 
 size_t beam_workspace_bytes(int B, int T, int beam) {
@@ -675,7 +1020,11 @@ int launch_beam(const BeamParams& p, hipStream_t stream) {
   // CHIRON_BEAM_GENERIC=1 forces the literal sequential kernel (the tests use it to cross-check the two)
   const char* fg = getenv("CHIRON_BEAM_GENERIC");
   const bool force_generic = fg && fg[0] == '1';
-  if (p.beam <= 64 && p.T < 8192 && !force_generic)   // T: the depth field of the register kernel's packed entry
+  const char* f1 = getenv("CHIRON_BEAM_SINGLE");     // =1: one window per wave for every width (A/B switch and test partner)
+  const bool single = f1 && f1[0] == '1';
+  if (p.beam <= 32 && p.T < 8192 && !force_generic && !single)
+    hipLaunchKernelGGL(beam32x2_kernel, dim3((p.B + 1) / 2), dim3(64), 0, stream, p, node_cap);
+  else if (p.beam <= 64 && p.T < 8192 && !force_generic)   // T: the depth field of the register kernel's packed entry
     hipLaunchKernelGGL(beam64_kernel, dim3(p.B), dim3(64), 0, stream, p, node_cap);
   else
     hipLaunchKernelGGL(beam_kernel, dim3(p.B), dim3(64), beam_smem_bytes(p.beam), stream, p, node_cap);

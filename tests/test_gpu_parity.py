@@ -822,10 +822,11 @@ def test_decoded_sparse_tensor_of_a_quarter_million_entries(dna):
 
 
 def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
-    """beam <= 64 runs the event-driven in-register kernel (beam.hip beam64_kernel); CHIRON_BEAM_GENERIC=1
-    forces the literal sequential walk.  Both restate the same TF Step() order, so they must agree bit for
-    bit -- on flat posteriors (many insertions and evictions per frame, the order-dependent regime), on
-    peaked ones, and on ragged lengths."""
+    """beam <= 64 runs the event-driven in-register kernel (beam.hip beam64_kernel; up to 32 the two-windows-per-wave
+    form beam32x2_kernel); CHIRON_BEAM_GENERIC=1 forces the literal sequential walk, CHIRON_BEAM_SINGLE=1 one window per
+    wave.  All restate the same TF Step() order, so they must agree bit for bit -- on flat posteriors (many insertions
+    and evictions per frame, the order-dependent regime), on peaked ones, on fully tied ones, on ragged lengths
+    (neighbouring windows of very different lengths share a wave) and on an odd number of windows."""
     spec, w = dna
     rng = np.random.RandomState(11)
     B, T = 96, 400
@@ -847,7 +848,20 @@ def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
                 assert np.array_equal(a[1], g.decoded.values), beam
                 assert np.array_equal(a[2], np.array(g.decoded.dense_shape)), beam
                 assert np.array_equal(a[3], g.log_prob), beam
+                monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
+                if beam <= 32:   # widths up to 32 run two windows per wave (beam32x2_kernel); CHIRON_BEAM_SINGLE=1: one per wave
+                    monkeypatch.setenv("CHIRON_BEAM_SINGLE", "1")
+                    o = eng.decode(lg, sl, beam_width=beam)
+                    monkeypatch.delenv("CHIRON_BEAM_SINGLE", raising=False)
+                    assert np.array_equal(a[0], o.decoded.indices) and np.array_equal(a[1], o.decoded.values), beam
+                    assert np.array_equal(a[3], o.log_prob), beam
+                    # an odd number of windows (the last wave's upper half has none), neighbours of very different lengths
+                    odd = eng.decode(lg[:B - 1], sl[:B - 1], beam_width=beam)
+                    keep = a[0][:, 0] < B - 1
+                    assert np.array_equal(odd.decoded.indices, a[0][keep]) and np.array_equal(odd.decoded.values, a[1][keep]), beam
+                    assert np.array_equal(odd.log_prob, a[3][:B - 1]), beam
     monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
+    monkeypatch.delenv("CHIRON_BEAM_SINGLE", raising=False)
 
 
 def test_head_rna_models_with_stem(built):
