@@ -1020,8 +1020,11 @@ int launch_beam(const BeamParams& p, hipStream_t stream) {
   // CHIRON_BEAM_GENERIC=1 forces the literal sequential kernel (the tests use it to cross-check the two)
   const char* fg = getenv("CHIRON_BEAM_GENERIC");
   const bool force_generic = fg && fg[0] == '1';
-  const char* f1 = getenv("CHIRON_BEAM_SINGLE");     // =1: one window per wave for every width (A/B switch and test partner)
-  const bool single = f1 && f1[0] == '1';
+  // Two windows per wave pay when the windows outnumber the chip's SIMDs by enough for issue slots to count; a small batch
+  // is latency-bound and finishes sooner with a wave per window (1.55 against 1.99 ms for any batch up to 1024 windows alone
+  // on the chip).  CHIRON_BEAM_SINGLE=1: always one window per wave, =0: two whenever the width allows (A/B switch, tests).
+  const char* f1 = getenv("CHIRON_BEAM_SINGLE");
+  const bool single = f1 ? f1[0] == '1' : p.B < 512;
   if (p.beam <= 32 && p.T < 8192 && !force_generic && !single)
     hipLaunchKernelGGL(beam32x2_kernel, dim3((p.B + 1) / 2), dim3(64), 0, stream, p, node_cap);
   else if (p.beam <= 64 && p.T < 8192 && !force_generic)   // T: the depth field of the register kernel's packed entry

@@ -840,6 +840,7 @@ def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
         for lg in (flat, peaked, quant):
             for beam in (1, 2, 7, 30, 50, 64):
                 monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
+                monkeypatch.setenv("CHIRON_BEAM_SINGLE", "0")    # two windows per wave whatever the batch size (default: from 512 windows up)
                 a = eng.decode(lg, sl, beam_width=beam)
                 a = (a.decoded.indices.copy(), a.decoded.values.copy(), np.array(a.decoded.dense_shape), a.log_prob.copy())
                 monkeypatch.setenv("CHIRON_BEAM_GENERIC", "1")
@@ -856,6 +857,7 @@ def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
                     assert np.array_equal(a[0], o.decoded.indices) and np.array_equal(a[1], o.decoded.values), beam
                     assert np.array_equal(a[3], o.log_prob), beam
                     # an odd number of windows (the last wave's upper half has none), neighbours of very different lengths
+                    monkeypatch.setenv("CHIRON_BEAM_SINGLE", "0")
                     odd = eng.decode(lg[:B - 1], sl[:B - 1], beam_width=beam)
                     keep = a[0][:, 0] < B - 1
                     assert np.array_equal(odd.decoded.indices, a[0][keep]) and np.array_equal(odd.decoded.values, a[1][keep]), beam
