@@ -57,7 +57,7 @@ for row in list(csv.DictReader(open(f[0])))[:8]:
     print("%-70s calls %4s avg %9.1f us  %5s %%" % (row["Name"][:70], row["Calls"], float(row["AverageNs"]) / 1e3, row["Percentage"]))
 PY
 
-echo "--- PMC of beam64_kernel (16 launches: beam 30 / 50 on peaked and flat posteriors; per-launch means)" >> "$OUT/${R}_beam_kernel.txt"
+echo "--- PMC of beam32x2_kernel (beam 30: two windows per wave) and beam64_kernel (beam 50), 8 launches each on peaked and flat posteriors; per-launch means" >> "$OUT/${R}_beam_kernel.txt"
 bash tools/pmc_beam.sh "$OUT/pmc_beam" >> "$OUT/${R}_beam_kernel.txt" 2>> "$OUT/beam.err"
 
 # 6. fp16 engine at configs[4], kernel trace
