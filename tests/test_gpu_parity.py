@@ -838,7 +838,7 @@ def test_beam_register_kernel_equals_sequential_kernel(dna, monkeypatch):
     sl[:4] = [0, 1, 2, T]
     with ca.Engine(spec, w, max_batch=B, segment_len=400, max_beam=64) as eng:
         for lg in (flat, peaked, quant):
-            for beam in (1, 2, 7, 30, 50, 64):
+            for beam in (1, 2, 7, 30, 31, 32, 33, 50, 64):
                 monkeypatch.delenv("CHIRON_BEAM_GENERIC", raising=False)
                 monkeypatch.setenv("CHIRON_BEAM_SINGLE", "0")    # two windows per wave whatever the batch size (default: from 512 windows up)
                 a = eng.decode(lg, sl, beam_width=beam)
