@@ -228,3 +228,36 @@ def test_signal_text_writer_and_extract_records(tmp_path):
     assert np.array_equal(recs[0][1], signal_io.read_signal(SIG))
     F.mode = "rna"
     assert np.array_equal(extract.extract_records(F5, F)[0][1], recs[0][1][::-1])
+
+
+def test_native_reader_with_and_without_libdeflate(tmp_path):
+    """The deflate filter goes through libdeflate when the box has libdeflate.so.0 (looked up with dlopen, once per process)
+    and through zlib otherwise or with CHIRON_NO_LIBDEFLATE=1: a child process with the switch set must read the same samples
+    as this process (chunked + deflate int16, several chunk sizes, a chunk that does not fill its last piece)."""
+    import hashlib
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import h5_writer
+    from chiron_amd import fast5 as f5
+    rng = np.random.RandomState(4)
+    paths = []
+    for i, (n, chunk) in enumerate(((100000, 20000), (12345, 4096), (70001, 70001))):
+        sig = (rng.randn(n) * 80 + 500).astype(np.int16)
+        pth = str(tmp_path / ("r%d.fast5" % i))
+        h5_writer.write_multi_read_fast5(pth, [("", "id-%d" % i, sig, None)], chunk=chunk)
+        paths.append((pth, hashlib.sha256(sig.astype(np.float32).tobytes()).hexdigest()))
+    code = ("import sys, hashlib, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from chiron_amd import fast5 as f5\n"
+            "for p in sys.argv[1:]:\n"
+            "    recs = f5.read_fast5_native(p)\n"
+            "    print(hashlib.sha256(np.asarray(recs[0]['signal'], dtype=np.float32).tobytes()).hexdigest())\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    want = [h for _, h in paths]
+    for env_extra in ({}, {"CHIRON_NO_LIBDEFLATE": "1"}):
+        env = dict(os.environ)
+        env.update(env_extra)
+        out = subprocess.run([sys.executable, "-c", code] + [p for p, _ in paths], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.split() == want, env_extra

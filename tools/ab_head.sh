@@ -12,5 +12,5 @@ objs=""
 for o in engine gemm stream16 stream32 wino lstm head_ctc beam bn_batch pwl consensus assemble fast5; do
   if [ $o = $SRC ]; then objs="$objs ../../build/${SRC}_$REV.o"; else objs="$objs $o.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/libchiron_${SRC}_$REV.so $objs -lz
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/libchiron_${SRC}_$REV.so $objs -lz -ldl
 echo build/libchiron_${SRC}_$REV.so
