@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CHIRON_AMD_LIB") or os.path.join(_HERE, "csrc", "libc
 MAX_BLOCKS = 8
 CLASSES = 5
 
-ABI_VERSION = 4      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
+ABI_VERSION = 5      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
@@ -74,6 +74,7 @@ SYMBOLS = [
     ("chiron_engine_device_results", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("chiron_engine_features", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("chiron_engine_rnn_output", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("chiron_engine_profile", C.c_int, [C.c_void_p, C.c_int32]),
     ("chiron_engine_profile_read", C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
     ("chiron_parse_signal_text", C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -96,7 +97,9 @@ SYMBOLS = [
     ("chiron_write_signal_text", C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p]),
     ("chiron_last_error", C.c_char_p, []),
     ("chiron_abi_version", C.c_int32, []),
+    ("chiron_build_flags", C.c_uint32, []),
 ]
+BUILD_TIMING = 1
 
 _lib = None
 
@@ -137,6 +140,12 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.chiron_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, this binding was written against %d: rebuild it"
+                          % (LIB_PATH, lib.chiron_abi_version(), ABI_VERSION))
+    if (lib.chiron_build_flags() & BUILD_TIMING) and os.environ.get("CHIRON_ALLOW_TIMING_BUILD") != "1":
+        raise ImportError("%s is a TIMING build (a kernel variant with parts switched off, csrc/timing_variants.h): its results "
+                          "are garbage.  Measurement tools set CHIRON_ALLOW_TIMING_BUILD=1; nothing else may load it." % LIB_PATH)
     _lib = lib
     return lib
 

@@ -53,6 +53,18 @@ chiron_status set_error(chiron_status st, const char* fmt, ...) {
 extern "C" const char* chiron_last_error(void) { return g_err; }
 extern "C" int32_t chiron_abi_version(void) { return CHIRON_ABI_VERSION; }
 
+// Objects built with CHIRON_TIMING_BUILD (timing_variants.h: parts of a kernel switched off, garbage results) register here from
+// a static constructor; the flag is constant-initialised, so the order of static initialisation does not matter.
+static int g_timing_build = 0;
+static char g_timing_source[96] = "";
+namespace chiron {
+void mark_timing_build(const char* source) {
+  g_timing_build = 1;
+  snprintf(g_timing_source, sizeof(g_timing_source), "%s", source ? source : "?");
+}
+}  // namespace chiron
+extern "C" uint32_t chiron_build_flags(void) { return g_timing_build ? CHIRON_BUILD_TIMING : 0u; }
+
 static int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 // TF 'SAME' padding: out = ceil(W/s), pad_total = max((out-1)s + k - W, 0), left = total/2
@@ -217,6 +229,10 @@ struct Slot {
   int batch = 0;
   uint32_t flags = 0;
   const float* sig_used = nullptr;
+  // what chiron_engine_features / chiron_engine_rnn_output may hand out: the batch size of the last NETWORK batch of this slot
+  // (0 after a decode-only batch or a failed submit: `batch` alone also counts chiron_engine_decode, which runs no network)
+  int net_batch = 0;
+  const float* rnn_out = nullptr;   // the last layer's lasth (time-major [T][BP][lasth_ld]; halves in an f16 engine)
   std::vector<ProfEvent> events;
 };
 
@@ -1279,6 +1295,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
       }
     }
   }
+  s->rnn_out = prev;
   FcParams f;
   f.lasth = prev;
   f.w = e->fc_w;
@@ -1399,10 +1416,12 @@ extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, co
   };
   const chiron_status st = enqueue();
   if (st) {
+    s->net_batch = 0;
     resync_tile_counters(s);
     return st;
   }
   s->batch = B;
+  s->net_batch = B;
   s->flags = flags;
   s->state.v.store(1, std::memory_order_release);
   return CHIRON_OK;
@@ -1438,6 +1457,7 @@ extern "C" chiron_status chiron_engine_decode(chiron_engine* e, int32_t slot, co
     return enqueue_decode(e, s, batch, beam_width, flags & ~CHIRON_WANT_LOGITS);
   };
   const chiron_status st = enqueue();
+  s->net_batch = 0;     // the slot's activations no longer belong to the batch it reports
   if (st) {
     hipStreamSynchronize(s->stream);
     return st;
@@ -1516,10 +1536,11 @@ extern "C" chiron_status chiron_engine_features(chiron_engine* e, int32_t slot, 
   if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range", slot);
   Slot* s = &e->slots[slot];
   if (s->state.v.load(std::memory_order_acquire) != 0) return fail(CHIRON_ERR_STATE, "slot %d holds an uncollected batch", slot);
-  if (s->batch < 1 || s->sig_used == nullptr) return fail(CHIRON_ERR_STATE, "slot %d has not run a batch through the network", slot);
+  if (s->net_batch < 1 || s->sig_used == nullptr)
+    return fail(CHIRON_ERR_STATE, "slot %d holds no network batch (nothing submitted yet, or its last batch was decode-only)", slot);
   if (e->split) return fail(CHIRON_ERR_INVALID, "chiron_engine_features: dtype fp32-split keeps features as hi/lo half pairs; not exported");
-  const size_t n = (size_t)s->batch * e->T * e->C;
-  if (out_batch) *out_batch = s->batch;
+  const size_t n = (size_t)s->net_batch * e->T * e->C;
+  if (out_batch) *out_batch = s->net_batch;
   if (out_channels) *out_channels = e->C;
   if (!out || cap_floats < n) return fail(CHIRON_ERR_OVERFLOW, "features need %zu floats, capacity %zu", n, cap_floats);
   HIP_TRY(hipSetDevice(e->opts.device_id));
@@ -1530,6 +1551,40 @@ extern "C" chiron_status chiron_engine_features(chiron_engine* e, int32_t slot, 
     for (size_t i = 0; i < n; ++i) out[i] = (float)h[i];
   } else {
     HIP_TRY(hipMemcpy(out, s->sig_used, n * 4, hipMemcpyDeviceToHost));
+  }
+  return CHIRON_OK;
+}
+
+// The recurrent stack's output (rnn.py:63-65 / :140-145, the tensor the FC head of rnn.py:72-96 reads), re-ordered from the
+// engine's time-major [T][BP][2H] to the reference's [batch, T, 2H].
+extern "C" chiron_status chiron_engine_rnn_output(chiron_engine* e, int32_t slot, float* out, size_t cap_floats, int32_t* out_batch,
+                                                  int32_t* out_width) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range", slot);
+  Slot* s = &e->slots[slot];
+  if (s->state.v.load(std::memory_order_acquire) != 0) return fail(CHIRON_ERR_STATE, "slot %d holds an uncollected batch", slot);
+  if (s->net_batch < 1 || s->rnn_out == nullptr)
+    return fail(CHIRON_ERR_STATE, "slot %d holds no network batch (nothing submitted yet, or its last batch was decode-only)", slot);
+  if (e->split) return fail(CHIRON_ERR_INVALID, "chiron_engine_rnn_output: not exported for dtype fp32-split");
+  const int B = s->net_batch, T = e->T, W = 2 * e->H, BP = e->BP, ld = e->lasth_ld;
+  const size_t n = (size_t)B * T * W;
+  if (out_batch) *out_batch = B;
+  if (out_width) *out_width = W;
+  if (!out || cap_floats < n) return fail(CHIRON_ERR_OVERFLOW, "the recurrent output needs %zu floats, capacity %zu", n, cap_floats);
+  HIP_TRY(hipSetDevice(e->opts.device_id));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  const size_t all = (size_t)T * BP * ld;
+  if (e->f16) {
+    std::vector<_Float16> h(all);
+    HIP_TRY(hipMemcpy(h.data(), s->rnn_out, all * 2, hipMemcpyDeviceToHost));
+    for (int t = 0; t < T; ++t)
+      for (int b = 0; b < B; ++b)
+        for (int k = 0; k < W; ++k) out[((size_t)b * T + t) * W + k] = (float)h[((size_t)t * BP + b) * ld + k];
+  } else {
+    std::vector<float> h(all);
+    HIP_TRY(hipMemcpy(h.data(), s->rnn_out, all * 4, hipMemcpyDeviceToHost));
+    for (int t = 0; t < T; ++t)
+      for (int b = 0; b < B; ++b) memcpy(out + ((size_t)b * T + t) * W, h.data() + ((size_t)t * BP + b) * ld, (size_t)W * 4);
   }
   return CHIRON_OK;
 }

@@ -165,8 +165,16 @@ struct H5 {
     if (!e) throw FormatError("unterminated name");
     return std::string(reinterpret_cast<const char*>(&d[s]), reinterpret_cast<const char*>(e));
   }
-  void walk_group_btree(uint64_t node, uint64_t heap, std::map<std::string, uint64_t>& out, int depth = 0) const {
+  // B-tree walks: a node of a damaged file may point back at itself or at an ancestor; depth alone would allow used^32 visits.
+  // No tree of a real file has more nodes than the file has 24-byte pieces.
+  void visit(uint64_t* budget) const {
+    if (*budget == 0) throw FormatError("B-tree has more nodes than the file can hold (a loop)");
+    --*budget;
+  }
+  uint64_t node_budget() const { return d.size() / 24 + 16; }
+  void walk_group_btree(uint64_t node, uint64_t heap, std::map<std::string, uint64_t>& out, uint64_t* budget, int depth = 0) const {
     if (depth > 32) throw FormatError("group B-tree too deep");
+    visit(budget);
     if (sig(node, "SNOD")) {
       const unsigned n = u16(node + 6);
       for (unsigned i = 0; i < n; ++i) {
@@ -178,13 +186,14 @@ struct H5 {
     if (!sig(node, "TREE") || u8(node + 4) != 0) throw FormatError("bad group B-tree node");
     const unsigned used = u16(node + 6);
     uint64_t p = node + 24;
-    for (unsigned i = 0; i < used; ++i, p += 16) walk_group_btree(base + u64(p + 8), heap, out, depth + 1);   // key(8) child(8) ...
+    for (unsigned i = 0; i < used; ++i, p += 16) walk_group_btree(base + u64(p + 8), heap, out, budget, depth + 1);   // key(8) child(8) ...
   }
   std::map<std::string, uint64_t> links(uint64_t addr) const {
     std::map<std::string, uint64_t> out;
     for (const Msg& m : messages(addr)) {
       if (m.type == 0x11) {
-        walk_group_btree(base + u64(m.off), base + u64(m.off + 8), out);
+        uint64_t budget = node_budget();
+        walk_group_btree(base + u64(m.off), base + u64(m.off + 8), out, &budget);
       } else if (m.type == 0x02) {   // Link Info: dense storage lives in a fractal heap
         const uint8_t flags = u8(m.off + 1);
         if (u64(m.off + 2 + ((flags & 1) ? 8 : 0)) != UNDEF) throw FormatError("dense (fractal heap) link storage is not supported");
@@ -232,11 +241,16 @@ struct H5 {
     const uint8_t bits0 = u8(off + 1);
     t.size = u32(off + 4);
     t.kind = cls;
+    // the element size comes from the file and divides / multiplies below (shuffle filter, byte counts): a damaged file must not
+    // reach that arithmetic with 0 or an absurd value
+    if (t.size == 0 || t.size > (1u << 20)) throw FormatError("datatype size " + std::to_string(t.size));
     if (cls == 0) {
       if (bits0 & 1) throw FormatError("big-endian integers are not supported");
+      if (t.size != 1 && t.size != 2 && t.size != 4 && t.size != 8) throw FormatError("integer size " + std::to_string(t.size));
       t.sign = (bits0 & 8) != 0;
     } else if (cls == 1) {
       if (bits0 & 1) throw FormatError("big-endian floats are not supported");
+      if (t.size != 4 && t.size != 8) throw FormatError("float size " + std::to_string(t.size));
     } else if (cls == 9) {
       if ((bits0 & 0x0F) != 1) throw FormatError("only variable-length strings are supported");
     } else if (cls != 3) {
@@ -249,6 +263,14 @@ struct H5 {
     std::vector<uint64_t> v(rank);
     for (int i = 0; i < rank; ++i) v[i] = u64(off + (ver == 1 ? 8 : 4) + 8ull * i);
     return v;
+  }
+  // element count of a dataspace; every product checked, and bounded so that count x (element size <= 8) and a cast to int64
+  // cannot wrap (a dimension of 2^63 in a damaged file used to pass the size guards after wrapping)
+  static uint64_t element_count(const std::vector<uint64_t>& dm) {
+    uint64_t n = 1;
+    for (uint64_t v : dm)
+      if (__builtin_mul_overflow(n, v, &n) || n > (1ull << 40)) throw FormatError("dataspace too large");
+    return n;
   }
   std::string vlen(const uint8_t* raw) const {   // 16-byte descriptor: length, collection address, object index
     uint32_t ln, idx;
@@ -263,7 +285,9 @@ struct H5 {
       const unsigned oi = u16(p);
       const uint64_t osz = u64(p + 8);
       if (oi == 0) break;
+      if (osz > end - (p + 16)) throw FormatError("global heap object runs past its collection");   // also keeps p increasing
       if (oi == idx) {
+        if (ln > osz) throw FormatError("variable-length string longer than its heap object");
         need(p + 16, ln);
         return std::string(reinterpret_cast<const char*>(&d[p + 16]), ln);
       }
@@ -316,8 +340,9 @@ struct H5 {
     uint32_t csize, fmask;
     uint64_t addr;
   };
-  void chunks(uint64_t node, int ndim, std::vector<Chunk>& out, int depth = 0) const {
+  void chunks(uint64_t node, int ndim, std::vector<Chunk>& out, uint64_t* budget, int depth = 0) const {
     if (depth > 32) throw FormatError("chunk B-tree too deep");
+    visit(budget);
     if (!sig(node, "TREE") || u8(node + 4) != 1) throw FormatError("bad chunk B-tree node");
     const int level = u8(node + 5);
     const unsigned used = u16(node + 6);
@@ -325,8 +350,12 @@ struct H5 {
     uint64_t p = node + 24;
     for (unsigned i = 0; i < used; ++i, p += ksz + 8) {
       const uint64_t child = base + u64(p + ksz);
-      if (level == 0) out.push_back(Chunk{u64(p + 8), u32(p), u32(p + 4), child});
-      else chunks(child, ndim, out, depth + 1);
+      if (level == 0) {
+        visit(budget);                       // a chunk record is 24+ bytes of the file as well
+        out.push_back(Chunk{u64(p + 8), u32(p), u32(p + 4), child});
+      } else {
+        chunks(child, ndim, out, budget, depth + 1);
+      }
     }
   }
   // raw bytes of a dataset (+ its datatype and element count)
@@ -357,10 +386,9 @@ struct H5 {
     if (!layout || !have_dt || !have_dims) throw FormatError("not a dataset");
     (void)lsize;
     if (u8(layout) != 3) throw FormatError("data layout message version " + std::to_string(u8(layout)));
-    uint64_t n = 1;
-    for (uint64_t v : dm) n *= v;
-    const uint64_t total = n * t.size;
-    if (total > (1ull << 34)) throw FormatError("dataset too large");
+    const uint64_t n = element_count(dm);
+    uint64_t total;
+    if (__builtin_mul_overflow(n, (uint64_t)t.size, &total) || total > (1ull << 34)) throw FormatError("dataset too large");
     const int cls = u8(layout + 1);
     std::vector<uint8_t> raw;
     if (cls == 0) {
@@ -382,7 +410,8 @@ struct H5 {
         if (f != 1 && f != 2) throw FormatError("unsupported filter " + std::to_string(f));
       raw.assign(total, 0);
       std::vector<Chunk> cks;
-      if (btree != UNDEF) chunks(base + btree, ndim, cks);
+      uint64_t budget = node_budget();
+      if (btree != UNDEF) chunks(base + btree, ndim, cks, &budget);
       std::vector<uint8_t> a, b;
       for (const Chunk& c : cks) {
         need(c.addr, c.csize);
@@ -415,10 +444,10 @@ struct H5 {
             a.swap(b);
           }
         }
-        const uint64_t s = c.off0 * t.size;
-        if (s >= total) continue;
-        const uint64_t e = std::min<uint64_t>(s + cbytes, total);
-        memcpy(raw.data() + s, a.data(), std::min<uint64_t>(e - s, a.size()));
+        uint64_t s;
+        if (__builtin_mul_overflow(c.off0, (uint64_t)t.size, &s) || s >= total) continue;
+        const uint64_t room = std::min<uint64_t>(cbytes, total - s);     // never s + cbytes: that sum can wrap
+        memcpy(raw.data() + s, a.data(), std::min<uint64_t>(room, a.size()));
       }
     } else {
       throw FormatError("layout class " + std::to_string(cls));
@@ -431,9 +460,7 @@ struct H5 {
   int64_t dataset_count(uint64_t addr) const {   // element count without reading the data
     for (const Msg& m : messages(addr))
       if (m.type == 0x01) {
-        uint64_t n = 1;
-        for (uint64_t v : dims(m.off)) n *= v;
-        return (int64_t)n;
+        return (int64_t)element_count(dims(m.off));
       }
     throw FormatError("not a dataset");
   }
@@ -558,7 +585,9 @@ extern "C" chiron_status chiron_fast5_signal(const chiron_fast5* f, int32_t i, f
     DType t;
     uint64_t n = 0;
     const std::vector<uint8_t> raw = f->h5.dataset(f->reads[i].signal_addr, &t, &n);
-    if ((int64_t)n > cap) return chiron::set_error(CHIRON_ERR_OVERFLOW, "chiron_fast5_signal: %llu samples, capacity %lld", (unsigned long long)n, (long long)cap);
+    if (cap < 0 || n > (uint64_t)cap) return chiron::set_error(CHIRON_ERR_OVERFLOW, "chiron_fast5_signal: %llu samples, capacity %lld", (unsigned long long)n, (long long)cap);
+    if (t.kind != 0 && t.kind != 1) throw FormatError("the Signal dataset is not numeric");
+    if (raw.size() / t.size < n) throw FormatError("dataset shorter than its dataspace");
     auto put = [&](uint64_t k, float v) { out[reverse ? n - 1 - k : k] = v; };
     const uint8_t* p = raw.data();
     if (t.kind == 0) {

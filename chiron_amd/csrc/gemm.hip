@@ -16,6 +16,7 @@
 //                        operand relu(sig*a[c]+b[c]) is computed in the loader, and shapes the DMA kernel is not
 //                        instantiated for.
 #include "kernels.h"
+#include "timing_variants.h"
 
 #include <type_traits>
 
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
 #pragma unroll
                   for (int ni = 0; ni < NNI; ++ni) {
                     const f32x16 c = acc[mi][ni];
-#if defined(CHIRON_SENS) && (CHIRON_SENS & 16)
+#if CHIRON_SENS & 16
                     if (j & 1) { acc[mi][ni][0] += a[mi][j] * b[ni][j]; continue; }   // timing experiment: half of the MFMAs
 #endif
                     acc[mi][ni] = ZOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], c, 0, 0, 0)

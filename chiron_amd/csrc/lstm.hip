@@ -22,6 +22,7 @@
 //   t = seq_len-1-s per row (tf.reverse_sequence folded into index arithmetic, no copy): its z is stored by step
 //   by the projection GEMM, its output frame index is per-lane arithmetic.
 #include "kernels.h"
+#include "timing_variants.h"
 
 #include <algorithm>
 
@@ -43,17 +44,63 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // every write, SQ_LDS_BANK_CONFLICT 0.73 of the LDS cycles).
 constexpr int HG = 8 * 64;  // floats per group and buffer (q = 7 is never used: K = 100 < 112)
 
-// Gate math on the hardware exp2 / rcp.  The four pre-activations are scaled two at a time (v_pk_mul_f32) and the
-// "+ 1" of the four denominators added two at a time (v_pk_add_f32): every VALU instruction of the step is paid in
-// matrix-pipe time (tools/ubench/mfma_valu_overlap.hip).
-//   sigmoid(x) = 1 / (1 + 2^(-x log2 e)),  tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1)   (saturates correctly at +-inf)
+// Gate math.  Three forms, chosen at compile time (CHIRON_GATE_MATH; tools/variants.sh --product builds the others for A/B runs
+// and for the per-stage error budget of tools/parity_budget.py):
+//   0  hardware exp2 / rcp, tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1): the cheapest form (rounds 1 .. 3).  Its tanh carries an
+//      ABSOLUTE error of an ulp of 1 .. 2 (1.2e-7 .. 2.4e-7) whatever |x| is, where libm's is relative to tanh(x);
+//   1  the same exp2 / rcp with one Newton step on every reciprocal, and tanh through the odd, cancellation-free form
+//      tanh|x| = (1 - e) / (1 + e), e = 2^(-2 |x| log2 e) (1 - e is exact for e >= 1/2 and never loses more than an ulp of e);
+//   2  libm: expf / tanhf and IEEE division -- what a float32 numpy restatement computes; the yardstick.
+// The four pre-activations are scaled two at a time (v_pk_mul_f32) and the "+ 1" of the denominators added two at a time
+// (v_pk_add_f32): every VALU instruction of the step is paid in matrix-pipe time (tools/ubench/mfma_valu_overlap.hip).
+//   sigmoid(x) = 1 / (1 + 2^(-x log2 e))   (saturates correctly at +-inf in every form)
+#ifndef CHIRON_GATE_MATH
+#define CHIRON_GATE_MATH 0
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float LOG2E = 1.4426950408889634f;
+#if CHIRON_GATE_MATH == 1
+__device__ __forceinline__ float rcp_newton(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  // r' = r + r (1 - d r); d = inf gives r = 0 and 1 - inf * 0 = NaN, so the correction is dropped there (v_cndmask on a class test
+  // would cost more than guarding with the finite test the compiler turns into v_cmp_class)
+  const float e = fmaf(-d, r, 1.0f);
+  const float r2 = fmaf(r, e, r);
+  return __builtin_isfinite(d) ? r2 : r;
+}
+__device__ __forceinline__ float sym_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(x) * (-2.0f * LOG2E));      // (0, 1]
+  const float t = (1.0f - e) * rcp_newton(1.0f + e);
+  return __builtin_copysignf(t, x);
+}
+#endif
 __device__ __forceinline__ float fast_tanh(float x) {
+#if CHIRON_GATE_MATH == 2
+  return tanhf(x);
+#elif CHIRON_GATE_MATH == 1
+  return sym_tanh(x);
+#else
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * (2.0f * LOG2E)) + 1.0f), 1.0f);
+#endif
 }
 // q = (i, j, f, o) pre-activations, c = previous cell state  ->  new cell state; *h_out = new output
 __device__ __forceinline__ float lstm_cell(f32x4 q, float c, float* h_out) {
+#if CHIRON_GATE_MATH == 2
+  const float si = 1.0f / (1.0f + expf(-q[0])), sf = 1.0f / (1.0f + expf(-q[2])), so = 1.0f / (1.0f + expf(-q[3]));
+  const float tj = tanhf(q[1]);
+  const float cn = fmaf(sf, c, si * tj);
+  *h_out = so * tanhf(cn);
+  return cn;
+#elif CHIRON_GATE_MATH == 1
+  const f32x2 e_if = (f32x2){q[0], q[2]} * (f32x2){-LOG2E, -LOG2E};
+  const f32x2 d_if = (f32x2){__builtin_amdgcn_exp2f(e_if[0]), __builtin_amdgcn_exp2f(e_if[1])} + (f32x2){1.0f, 1.0f};
+  const float d_o = __builtin_amdgcn_exp2f(q[3] * -LOG2E) + 1.0f;
+  const float si = rcp_newton(d_if[0]), sf = rcp_newton(d_if[1]), so = rcp_newton(d_o);
+  const float tj = sym_tanh(q[1]);
+  const float cn = fmaf(sf, c, si * tj);
+  *h_out = so * sym_tanh(cn);
+  return cn;
+#else
   // the pairs are the register-adjacent ones, (i, j) and (f, o): the accumulators of the 16-row forms deliver the four gates in
   // consecutive registers, and pairing (i, f) / (o, j) cost five moves per cell to build the packed operands
   const f32x2 e_ij = (f32x2){q[0], q[1]} * (f32x2){-LOG2E, 2.0f * LOG2E};
@@ -66,6 +113,7 @@ __device__ __forceinline__ float lstm_cell(f32x4 q, float c, float* h_out) {
   const float cn = fmaf(sf, c, si * tj);
   *h_out = so * fast_tanh(cn);
   return cn;
+#endif
 }
 
 // 4x4 transpose between the register index and lane bits [5:4], in registers: (lane = gate*16 + unit, reg = row) ->
@@ -665,9 +713,7 @@ static __device__ __forceinline__ _Float16* lstm16f_xtiles() {
 static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, _Float16* dst, unsigned off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
 }
-#ifndef CHIRON_F16F_VARIANT
-#define CHIRON_F16F_VARIANT 0   // timing experiments only (tools/variants.sh), bit mask: 1 no gate math, 2 no MFMAs, 4 no output stores, 8 no x prefetch, 16 no x tile reads, 32 no h tile reads, 64 no h tile writes
-#endif
+// CHIRON_F16F_VARIANT (timing_variants.h): instrumented builds of this kernel, 0 in the product
 template <int KSX, int NG>
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParams p) {
   // NG = 2: one workgroup carries TWO 16-row groups through the same weight registers (every weight fragment feeds two
@@ -1046,9 +1092,6 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32w_kernel(const LstmParam
     f32x4 acc[W16_NT];
 #pragma unroll
     for (int n = 0; n < W16_NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifndef CHIRON_W32_VARIANT
-#define CHIRON_W32_VARIANT 0   // timing experiments only (tools/variants.sh): 1 no gate math, 2 no MFMAs, 3 no transpose
-#endif
 #if CHIRON_W32_VARIANT == 2
 #pragma unroll
     for (int n = 0; n < W16_NT; ++n) acc[n][0] = hv[n] + w[n][0] + hv[n + 8] + hv[24];
@@ -1134,9 +1177,6 @@ constexpr int W32_PK = 8;   // k-steps of tile 24 per partial wave (waves 0, 1, 
 //   * tile 24's partial products sit under a wave-uniform branch per 8-k-step chunk, not per k-step.
 #define W32_ZLOAD(dst, vo, off) asm volatile("global_load_dword %0, %1, %2 offset:" #off : "=v"(dst) : "v"(vo), "s"(zs) : "memory")
 
-#ifndef CHIRON_SENS
-#define CHIRON_SENS 0
-#endif
 __device__ __forceinline__ float sens_cell(f32x4 q, float c, float* h_out) {
 #if CHIRON_SENS & 1
   const float cn = 0.25f * (q[0] + q[1]) + 0.5f * c;

@@ -15,6 +15,7 @@
 // C_in = C_out = 256, stride 1 (res_layer2 / res_layer3 of DNA_default and their RNA counterparts); every other shape keeps
 // gemm.hip.
 #include "kernels.h"
+#include "timing_variants.h"
 
 #include <algorithm>
 
@@ -47,9 +48,7 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t s_rsrc(const void* base
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, S_RECORDS, 0x00027000);
 }
 
-#ifndef CHIRON_S16_VARIANT
-#define CHIRON_S16_VARIANT 0   // timing experiments only (tools/variants.sh), bit mask: 1 no output stores, 2 no input DMA
-#endif
+// CHIRON_S16_VARIANT (timing_variants.h): instrumented builds of these kernels, 0 in the product
 // Round 3: both sides of the kernel move WHOLE 512-byte rows per instruction.  Round 2 fetched 32 bytes of each of 32 rows per
 // DMA instruction (octet-major tiles) and stored 16 bytes of each of 32 rows per store instruction: instrumented builds at
 // B = 4096 (0.84 GB in, 0.84 GB out): 0.418 ms, without the stores 0.219, without the loads 0.257, without both 0.194 -- the
@@ -187,9 +186,7 @@ __global__ __launch_bounds__(64 * S_NW, 1) void conv1x1_f16_stream_kernel(const 
       f16x8 xb[16];   // the whole K-segment of this lane's row: sixteen reads in flight, the products follow as they arrive
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const f16x8*>(base + sg * (S_TILE_H * 2) + (rd0 ^ (unsigned)(ks * 32)));
-#ifndef CHIRON_S16_NOFENCE
       asm volatile("" ::: "memory");   // all sixteen reads are issued before the first product waits for one (the scheduler pairs them up otherwise)
-#endif
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[sg][ks], xb[ks], acc, 0, 0, 0);
     }

@@ -25,6 +25,7 @@
 //   ReLU, two 16-byte stores per channel quad.
 // Differs from the direct form by fp32 rounding only (the transforms re-associate the sum over taps).
 #include "kernels.h"
+#include "timing_variants.h"
 
 namespace chiron {
 
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
         const int e = 4 * q + r;
         const float m0_ = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
         const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-#if defined(CHIRON_SENS) && (CHIRON_SENS & 4)
+#if CHIRON_SENS & 4
         y0[r] = m0_ + m4, y1[r] = m1, y2[r] = m2 + m5, y3[r] = m3 + s4[r];   // timing experiment: no output transform
 #else
         y0[r] = ((m0_ + s12) + s34) + s4[r];
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
           v[4][2 * h] = w4[0], v[4][2 * h + 1] = w4[1];
           v[5][2 * h] = w5[0], v[5][2 * h + 1] = w5[1];
         }
-#if defined(CHIRON_SENS) && (CHIRON_SENS & 2)
+#if CHIRON_SENS & 2
         v[0] = d0, v[1] = d1, v[2] = d2, v[3] = d3, v[4] = d4, v[5] = d5;   // timing experiment: no input transform
 #endif
         if (go) issue_part(g, nc, nxt);

@@ -158,6 +158,16 @@ class Engine(object):
         _lib.check(self._lib.chiron_engine_features(self._h, slot, out.ctypes.data_as(C.c_void_p), out.size, C.byref(b), C.byref(c)))
         return out
 
+    def rnn_output(self, slot=0):
+        """`lasth` (rnn.py:63-65 / :140-145): the recurrent stack's output [batch, T, 2H] of the batch last run on the (idle) slot."""
+        b, w = C.c_int32(), C.c_int32()
+        st = self._lib.chiron_engine_rnn_output(self._h, slot, None, 0, C.byref(b), C.byref(w))
+        if st != _lib.ERR_OVERFLOW:
+            _lib.check(st)
+        out = np.empty((b.value, self.T, w.value), dtype=np.float32)
+        _lib.check(self._lib.chiron_engine_rnn_output(self._h, slot, out.ctypes.data_as(C.c_void_p), out.size, C.byref(b), C.byref(w)))
+        return out
+
     def sync(self):
         _lib.check(self._lib.chiron_engine_sync(self._h))
 

@@ -90,8 +90,16 @@ class _H5File(object):
         p = node + 24
         for i in range(used):
             child, = struct.unpack_from("<Q", d, p + 8)        # key(8) child(8) key(8) ...
+            self._visit()
             self._walk_group_btree(self.base + child, heap, out)
             p += 16
+
+    def _visit(self):
+        """A B-tree of a damaged file may point back at itself: no real tree has more nodes than the file has 24-byte
+        pieces (the same budget as csrc/fast5.cpp)."""
+        self._budget -= 1
+        if self._budget < 0:
+            raise Fast5FormatError("B-tree has more nodes than the file can hold (a loop)")
 
     def links(self, addr):
         """children of the group whose object header is at addr: {name: object header address}.
@@ -101,6 +109,7 @@ class _H5File(object):
         for mtype, _, body in self.messages(addr):
             if mtype == 0x11:
                 btree, heap = struct.unpack_from("<QQ", body, 0)
+                self._budget = len(self.d) // 24 + 16          # per walk
                 self._walk_group_btree(self.base + btree, self.base + heap, out)
             elif mtype == 0x02:            # Link Info: dense storage lives in a fractal heap
                 flags = body[1]
@@ -142,6 +151,8 @@ class _H5File(object):
         cls = body[0] & 0x0F
         bits0 = body[1]
         size, = struct.unpack_from("<I", body, 4)
+        if size == 0 or size > (1 << 20) or (cls == 0 and size not in (1, 2, 4, 8)) or (cls == 1 and size not in (4, 8)):
+            raise Fast5FormatError("datatype size %d" % size)
         if cls == 0:
             if bits0 & 1:
                 raise Fast5FormatError("big-endian integers are not supported")
@@ -174,6 +185,8 @@ class _H5File(object):
             oi, _, _, osz = struct.unpack_from("<HHIQ", d, p)
             if oi == 0:
                 break
+            if osz > end - (p + 16):
+                raise Fast5FormatError("global heap object runs past its collection")
             if oi == idx:
                 return d[p + 16:p + 16 + ln]
             p += 16 + _pad8(osz)
@@ -234,6 +247,7 @@ class _H5File(object):
             csize, fmask = struct.unpack_from("<II", d, p)
             offs = struct.unpack_from("<%dQ" % ndim, d, p + 8)
             child, = struct.unpack_from("<Q", d, p + ksz)
+            self._visit()
             if level == 0:
                 out.append((offs, csize, fmask, self.base + child))
             else:
@@ -267,7 +281,12 @@ class _H5File(object):
         if layout[0] != 3:
             raise Fast5FormatError("data layout message version %d" % layout[0])
         cls = layout[1]
-        total = (int(np.prod(dims)) if dims else 1) * esize
+        count = 1
+        for v in dims:
+            count *= int(v)                  # Python integers: no wrap, but a damaged dimension must not reach bytearray()
+        total = count * esize
+        if count > (1 << 40) or total > (1 << 34):
+            raise Fast5FormatError("dataset too large")
         if cls == 0:
             sz, = struct.unpack_from("<H", layout, 2)
             raw = layout[4:4 + sz]
@@ -284,6 +303,7 @@ class _H5File(object):
                 raise Fast5FormatError("unsupported filter %s" % filters)
             buf = bytearray(total)
             chunks = []
+            self._budget = len(self.d) // 24 + 16
             if btree != UNDEF:
                 self._chunks(self.base + btree, ndim, chunks)
             cbytes = cdims[0] * esize

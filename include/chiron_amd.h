@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CHIRON_ABI_VERSION 4
+#define CHIRON_ABI_VERSION 5
 #define CHIRON_MAX_BLOCKS 8
 #define CHIRON_CLASSES 5 /* A,C,G,T,blank (rnn.py:25 class_n=5) */
 
@@ -204,6 +204,14 @@ chiron_status chiron_engine_device_results(chiron_engine* e, int32_t slot, const
 chiron_status chiron_engine_features(chiron_engine* e, int32_t slot, float* out, size_t cap_floats, int32_t* out_batch,
                                      int32_t* out_channels);
 
+/* The recurrent stack's output, rnn.py:63-65 (DNA: stack_bidirectional_dynamic_rnn) / rnn.py:140-145 (RNA: MultiRNNCell inside
+ * bidirectional_dynamic_rnn) -- `lasth`, the tensor the FC head of rnn.py:72-96 reads: [batch, T, 2 * hidden] float32 ([..., :H]
+ * forward, [..., H:] backward; frames at or past a row's seq_len are 0), of the batch most recently run on `slot` (idle).  Same
+ * protocol and status codes as chiron_engine_features.  With a model descriptor of 1 or 2 rnn_layers it is the output of that
+ * layer: the per-stage error budget of the parity tests (tools/parity_budget.py) is built on it.                        */
+chiron_status chiron_engine_rnn_output(chiron_engine* e, int32_t slot, float* out, size_t cap_floats, int32_t* out_batch,
+                                       int32_t* out_width);
+
 /* Per-kernel timing with HIP events on the engine's own streams (bench.py
  * roofline).  Enable, run, sync, then read.                                    */
 typedef struct {
@@ -307,6 +315,11 @@ chiron_status chiron_crc32c(const void* data, size_t len, uint32_t* out);
 
 const char* chiron_last_error(void);
 int32_t chiron_abi_version(void);
+/* What kind of build this library is.  CHIRON_BUILD_TIMING: at least one object was compiled as a timing-only kernel variant
+ * (csrc/timing_variants.h: parts of a kernel switched off to measure what they cost) -- its results are GARBAGE; the Python
+ * binding refuses such a library unless CHIRON_ALLOW_TIMING_BUILD=1.  0 for the product.                               */
+#define CHIRON_BUILD_TIMING 1u
+uint32_t chiron_build_flags(void);
 
 #ifdef __cplusplus
 }

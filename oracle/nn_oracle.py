@@ -188,6 +188,28 @@ def rnn_forward(fea, seq_len, spec, weights):
     return np.concatenate(outs, axis=2)
 
 
+def rnn_layer_forward(x, seq_len, spec, weights, layer):
+    """ONE layer of the recurrent stack as a stage of its own: x = the previous stage's output ([B,T,C] features for layer 0,
+    [B,T,2H] after that) -> [B,T,2H].  'stack' (rnn.py:63-65): both directions read the whole x.  'multi' (rnn.py:140-145):
+    above layer 0 the forward cell reads x[..., :H] and the backward cell x[..., H:]; the backward stack lives in the
+    reversed domain, and reversing a layer's output and the next layer's input again is the identity on the first seq_len
+    frames (the rest is zero either way), so composing these stages equals rnn_forward bit for bit (tests/test_oracle_nn.py).
+    The per-stage error budget (tools/parity_budget.py) applies this float64 stage to an implementation's own previous-stage
+    output: what remains is the error BORN in the stage."""
+    r = spec["rnn"]
+    H = r["hidden"]
+    outs = []
+    for di, (d, rev) in enumerate((("fw", False), ("bw", True))):
+        if r["kind"] == "stack":
+            p = "BDLSTM_rnn/cell_%d/bidirectional_rnn/%s/lstm_cell/" % (layer, d)
+            xin = x
+        else:
+            p = "BDGRU_rnn/%s/multi_rnn_cell/cell_%d/lstm_cell/" % (d, layer)
+            xin = x if layer == 0 else x[:, :, di * H:(di + 1) * H]
+        outs.append(lstm_direction(np.ascontiguousarray(xin), seq_len, weights[p + "kernel"], weights[p + "bias"], rev))
+    return np.concatenate(outs, axis=2)
+
+
 def reverse_sequence(x, seq_len):
     """tf.reverse_sequence(seq_dim=1, batch_dim=0): only the first seq_len[b]
     frames of each row are reversed, the tail stays in place."""

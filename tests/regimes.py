@@ -85,3 +85,14 @@ def trained_like_weights(spec, x_calib, seed=5, lstm_gain=3.0, gate_spread=3.0, 
             nin = w[k].shape[0] - spec.hidden
             w[k][:nin] = (w[k][:nin] / max(s, 1e-6) * 0.75).astype(np.float32)
     return w, fea
+
+
+def peaked_head(w, gain=4.0, blank_bias=2.0):
+    """Trained-CTC-like posteriors on top of any weight set: class layer x gain and the blank ahead by default, so that most
+    frames are decided by a wide margin (blank, or one base on evidence) -- as a trained model's are."""
+    w = dict(w)
+    w["rnn_fnn_layer/weights_class"] = (w["rnn_fnn_layer/weights_class"] * gain).astype(np.float32)
+    bc = w["rnn_fnn_layer/bias_class"].copy()
+    bc[4] += blank_bias
+    w["rnn_fnn_layer/bias_class"] = bc
+    return w

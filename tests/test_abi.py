@@ -23,7 +23,52 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == bound, "binding and header disagree: %s" % (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.chiron_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.chiron_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.chiron_build_flags() == 0          # the product library is never a timing build
+
+
+def test_timing_variants_cannot_ship_silently(built, tmp_path):
+    """csrc/timing_variants.h: a kernel source compiled with a timing switch (parts of the kernel off, garbage results) but
+    without CHIRON_TIMING_BUILD does not compile; with it, the library reports CHIRON_BUILD_TIMING and the binding refuses it
+    unless CHIRON_ALLOW_TIMING_BUILD=1.  Every garbage-result switch of the sources is declared in that one header."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "chiron_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    base = [hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    # stream32.hip has no timing switch of its own: compile a two-line source that includes the header
+    src = tmp_path / "probe.hip"
+    src.write_text('#include "timing_variants.h"\nint probe_value = CHIRON_SENS;\n')
+    bad = subprocess.run(base + ["-I", csrc, "-DCHIRON_SENS=1", "-c", str(src), "-o", str(tmp_path / "bad.o")], capture_output=True, text=True)
+    assert bad.returncode != 0 and "computes garbage" in bad.stderr
+    ok = subprocess.run(base + ["-I", csrc, "-DCHIRON_SENS=1", "-DCHIRON_TIMING_BUILD", "-c", str(src), "-o", str(tmp_path / "mark.o")],
+                        capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    objs = [os.path.join(csrc, o) for o in sorted(os.listdir(csrc)) if o.endswith(".o")]
+    lib_path = str(tmp_path / "libtiming.so")
+    ln = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, str(tmp_path / "mark.o")] + objs + ["-lz", "-ldl"],
+                        capture_output=True, text=True)
+    assert ln.returncode == 0, ln.stderr
+    code = "import sys; sys.path.insert(0, %r); from chiron_amd import _lib; print(_lib.load().chiron_build_flags())" % ROOT
+    env = dict(os.environ, CHIRON_AMD_LIB=lib_path)
+    env.pop("CHIRON_ALLOW_TIMING_BUILD", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "TIMING build" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, CHIRON_ALLOW_TIMING_BUILD="1"), capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "1", r.stderr
+    # no garbage-result switch outside the header: every "#if CHIRON_<X>" of the kernel sources names a macro the header declares
+    header = open(os.path.join(csrc, "timing_variants.h")).read()
+    declared = set(re.findall(r"#ifndef (CHIRON_[A-Z0-9_]+)", header))
+    assert declared == {"CHIRON_SENS", "CHIRON_W32_VARIANT", "CHIRON_F16F_VARIANT", "CHIRON_S16_VARIANT"}
+    product_forms = {"CHIRON_GATE_MATH"}           # compile-time choices that compute correct results (lstm.hip)
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".cpp", ".h")) and name != "timing_variants.h":
+            text = open(os.path.join(csrc, name)).read()
+            used = set(re.findall(r"#\s*(?:if|elif|ifdef|ifndef)[^\n]*?\b(CHIRON_[A-Z0-9_]+)", text))
+            used -= {"CHIRON_AMD_H", "CHIRON_TIMING_BUILD"}
+            assert used <= declared | product_forms, (name, used - declared)
+            if used & declared:
+                assert '#include "timing_variants.h"' in text, name
 
 
 def test_weights_size_and_validation(built):

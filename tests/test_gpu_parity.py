@@ -1246,11 +1246,7 @@ def test_f16_config5_full_batch_edit_distance_distribution(dna, regime):
     if regime == "peaked":
         import regimes
         w, _ = regimes.trained_like_weights(spec, x[:24], seed=5)
-        w = dict(w)
-        w["rnn_fnn_layer/weights_class"] = (w["rnn_fnn_layer/weights_class"] * 4.0).astype(np.float32)
-        bc = w["rnn_fnn_layer/bias_class"].copy()
-        bc[4] += 2.0                                   # blank ahead by default, bases win on evidence
-        w["rnn_fnn_layer/bias_class"] = bc
+        w = regimes.peaked_head(w)                     # class layer x 4, blank ahead by default: bases win on evidence
         logit_bound = 0.32
     with ca.Engine(spec, w, max_batch=B, segment_len=L) as e32:
         sl = ca.seq_len_for_engine(ln, e32.ratio)

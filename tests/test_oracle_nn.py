@@ -106,6 +106,28 @@ def test_multi_equals_manual_stack():
     np.testing.assert_allclose(out[:, :, :100], x, rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("kind", ["stack", "multi"])
+def test_layer_stages_compose_to_the_whole_stack(kind):
+    """nn_oracle.rnn_layer_forward (one recurrent layer as a stage: the per-stage error budget of tools/parity_budget.py applies
+    it to an implementation's own previous-stage output) composed over the layers == rnn_forward, bit for bit, float64 and
+    float32, ragged lengths including 0 and 1 -- for the MultiRNN graph too, where the backward stack is written as
+    reverse / 3 layers / reverse in rnn_forward and as a reversal around every layer here."""
+    import chiron_amd as ca
+    spec = ca.dna_default_spec() if kind == "stack" else ca.rna_default_spec()
+    sd = spec.to_dict()
+    w = ca.synthetic_weights(spec, seed=3, lstm_gain=2.0)
+    rng = np.random.RandomState(1)
+    fea = rng.randn(6, 23, 256)
+    sl = np.array([23, 11, 0, 1, 20, 23])
+    for dt in (np.float64, np.float32):
+        ww = {k: np.asarray(v, dtype=dt) for k, v in w.items()}
+        x = fea.astype(dt)
+        ref = no.rnn_forward(x, sl, sd, ww)
+        for l in range(3):
+            x = no.rnn_layer_forward(x, sl, sd, ww, l)
+        assert x.dtype == dt and np.array_equal(x, ref)
+
+
 def test_fc_head_formula():
     rng = np.random.RandomState(1)
     H, K = 100, 5
