@@ -51,6 +51,7 @@ constexpr int HG = 8 * 64;  // floats per group and buffer (q = 7 is never used:
 //   1  the same exp2 / rcp with one Newton step on every reciprocal, and tanh through the odd, cancellation-free form
 //      tanh|x| = (1 - e) / (1 + e), e = 2^(-2 |x| log2 e) (1 - e is exact for e >= 1/2 and never loses more than an ulp of e);
 //   2  libm: expf / tanhf and IEEE division -- what a float32 numpy restatement computes; the yardstick.
+//   3  form 0 with the odd tanh of form 1 and no Newton steps: two VALU instructions more per tanh than form 0.
 // The four pre-activations are scaled two at a time (v_pk_mul_f32) and the "+ 1" of the denominators added two at a time
 // (v_pk_add_f32): every VALU instruction of the step is paid in matrix-pipe time (tools/ubench/mfma_valu_overlap.hip).
 //   sigmoid(x) = 1 / (1 + 2^(-x log2 e))   (saturates correctly at +-inf in every form)
@@ -59,6 +60,13 @@ constexpr int HG = 8 * 64;  // floats per group and buffer (q = 7 is never used:
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float LOG2E = 1.4426950408889634f;
+#if CHIRON_GATE_MATH == 3
+__device__ __forceinline__ float sym_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(x) * (-2.0f * LOG2E));      // (0, 1]
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return __builtin_copysignf(t, x);
+}
+#endif
 #if CHIRON_GATE_MATH == 1
 __device__ __forceinline__ float rcp_newton(float d) {
   const float r = __builtin_amdgcn_rcpf(d);
@@ -77,7 +85,7 @@ __device__ __forceinline__ float sym_tanh(float x) {
 __device__ __forceinline__ float fast_tanh(float x) {
 #if CHIRON_GATE_MATH == 2
   return tanhf(x);
-#elif CHIRON_GATE_MATH == 1
+#elif CHIRON_GATE_MATH == 1 || CHIRON_GATE_MATH == 3
   return sym_tanh(x);
 #else
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * (2.0f * LOG2E)) + 1.0f), 1.0f);
@@ -96,6 +104,15 @@ __device__ __forceinline__ float lstm_cell(f32x4 q, float c, float* h_out) {
   const f32x2 d_if = (f32x2){__builtin_amdgcn_exp2f(e_if[0]), __builtin_amdgcn_exp2f(e_if[1])} + (f32x2){1.0f, 1.0f};
   const float d_o = __builtin_amdgcn_exp2f(q[3] * -LOG2E) + 1.0f;
   const float si = rcp_newton(d_if[0]), sf = rcp_newton(d_if[1]), so = rcp_newton(d_o);
+  const float tj = sym_tanh(q[1]);
+  const float cn = fmaf(sf, c, si * tj);
+  *h_out = so * sym_tanh(cn);
+  return cn;
+#elif CHIRON_GATE_MATH == 3
+  const f32x2 e_if = (f32x2){q[0], q[2]} * (f32x2){-LOG2E, -LOG2E};
+  const f32x2 d_if = (f32x2){__builtin_amdgcn_exp2f(e_if[0]), __builtin_amdgcn_exp2f(e_if[1])} + (f32x2){1.0f, 1.0f};
+  const float d_o = __builtin_amdgcn_exp2f(q[3] * -LOG2E) + 1.0f;
+  const float si = __builtin_amdgcn_rcpf(d_if[0]), sf = __builtin_amdgcn_rcpf(d_if[1]), so = __builtin_amdgcn_rcpf(d_o);
   const float tj = sym_tanh(q[1]);
   const float cn = fmaf(sf, c, si * tj);
   *h_out = so * sym_tanh(cn);

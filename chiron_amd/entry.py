@@ -65,7 +65,12 @@ def evaluation(args):
             # threads write raw/<name>.signal for the output tree and window the decoded samples straight away -- no
             # extract-everything barrier, no text parsed back.
             import os
+            from .extract import unique_read_files, logger
             prepare_folders(FLAGS, rank, world)
+            fast5_list, dropped = unique_read_files(fast5_list)       # before partitioning: every rank drops the same files
+            for lost, kept in (dropped if rank == 0 else []):
+                logger.error("Read name of %s is taken by %s as well: the reference's extraction would overwrite the first; only the "
+                             "second is basecalled." % (lost, kept))
             FLAGS.input = FLAGS.output + "/raw/"          # what the .meta files record (entry.py:38)
             sizes = {f: os.path.getsize(f) for f in fast5_list}
             FLAGS.fast5_files = shard.partition_reads(fast5_list, world, rank, sizes)

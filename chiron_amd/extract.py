@@ -92,6 +92,20 @@ def list_fast5(root_folder, recursive=True, test_number=None):
     return files[:test_number] if test_number else files
 
 
+def unique_read_files(files):
+    """Two fast5 files with the same basename in different sub-folders give ONE raw/<stem>.signal in the reference (the walk is
+    recursive, the output name is the stem: extract_sig_ref.py:62-79, :119): the later file overwrites the earlier and one read is
+    basecalled.  The direct path keys a read by that name as well, so both files would be windowed into one record -- mixed, or
+    never finished, and on different ranks they would race on the same output files.  Keep the LAST file of every stem (list_fast5
+    order, what overwriting leaves behind); -> (files kept, [(dropped, kept)])."""
+    last = {}
+    for f in files:
+        last[os.path.splitext(os.path.basename(f))[0]] = f
+    keep = [f for f in files if last[os.path.splitext(os.path.basename(f))[0]] == f]
+    dropped = [(f, last[os.path.splitext(os.path.basename(f))[0]]) for f in files if last[os.path.splitext(os.path.basename(f))[0]] != f]
+    return keep, dropped
+
+
 def prepare_folders(FLAGS, rank=0, world=1):
     """extract_sig_ref.py:43-56: raw/ reference/ log/ under the output folder, and the extraction log."""
     root_folder, out_folder = FLAGS.input_dir, FLAGS.output_dir

@@ -361,3 +361,47 @@ def test_crafted_damage_is_reported_never_a_crash_or_a_hang(tmp_path):
     blob[i:i + 8] = struct.pack("<Q", 16)
     open(p, "wb").write(bytes(blob))
     assert fast5.read_fast5_native(p)[0]["read_id"] == "read-one" == fast5.read_fast5(p)[0]["read_id"]
+
+
+def test_reference_rna_example_fast5_reproduce_their_digest():
+    """chiron/example_data/RNA/*.fast5 -- the reference's five RNA example reads (it ships no outputs for them): both readers give
+    the pinned read_id, sample count and SHA-256 of the int16 signal in acquisition order (tests/golden/example_rna/raw_digest.json,
+    written by make_example_rna_fixture.py, which also decodes every file WITHOUT any HDF5 structure -- zlib streams found by brute
+    force -- and requires the same samples); reverse = the RNA orientation `--mode rna` feeds the network (extract_sig_ref.py:165)."""
+    import hashlib
+    import json
+    ex = os.path.join(GOLDEN, "example_rna")
+    digest = json.load(open(os.path.join(ex, "raw_digest.json")))
+    assert len(digest) == 5
+    for name, d in digest.items():
+        p = os.path.join(ex, name)
+        py, nat = fast5.read_fast5(p), fast5.read_fast5_native(p)
+        assert len(py) == len(nat) == 1 and nat[0]["suffix"] == ""
+        for rec, sig in ((py[0], np.asarray(py[0]["signal"])), (nat[0], nat[0]["signal"])):
+            assert sig.size == d["samples"] and rec["read_id"] == d["read_id"] and rec["fastq"] == ""
+            assert hashlib.sha256(sig.astype("<i2").tobytes()).hexdigest() == d["sha256_int16le"]
+            assert sig[:5].tolist() == d["head"] and sig[-5:].tolist() == d["tail"] and sig.min() == d["min"] and sig.max() == d["max"]
+        assert np.array_equal(fast5.read_fast5_native(p, reverse=True)[0]["signal"], nat[0]["signal"][::-1])
+        ds = signal_io.read_data_for_eval(p, 0, step=1900, seg_length=2000, reverse_fast5=True)
+        assert ds.reads_n == d["windows_L2000_J1900"]
+        assert np.array_equal(np.asarray(ds.event[0][:5], dtype=np.float32), np.asarray(d["tail"][::-1], dtype=np.float32))
+
+
+def test_same_basename_in_two_subfolders_is_one_read(tmp_path):
+    """extract_sig_ref.py:62-79 walks recursively and names the output by the file stem: of two files with one basename the later
+    overwrites the earlier.  extract.unique_read_files keeps exactly that one for the direct path (which would otherwise merge both
+    files' windows under one read name)."""
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    files = []
+    for d in (a, b):
+        for n in ("x.fast5", "y.fast5" if d is a else "z.fast5"):
+            (d / n).write_bytes(b"")
+            files.append(str(d / n))
+    files.sort()
+    assert extract.list_fast5(str(tmp_path), True) == files
+    keep, dropped = extract.unique_read_files(files)
+    assert keep == [str(a / "y.fast5"), str(b / "x.fast5"), str(b / "z.fast5")]
+    assert dropped == [(str(a / "x.fast5"), str(b / "x.fast5"))]
+    assert extract.unique_read_files(keep) == (keep, [])

@@ -92,6 +92,21 @@ def local_reference(spec, w, stage, prev_impl, x, sl):
     return nn_oracle.fc_head(p, ww)
 
 
+def propagate_to_logits(spec, w, stage, impl_out, sl):
+    """the float64 oracle's REMAINING stages applied to an implementation's output of `stage`: the logits the network would give if
+    everything after that stage were exact -- their distance from the float64 logits is what the stages up to `stage` are
+    responsible for at the logits (errors born later are excluded; the network's own amplification is included)."""
+    sd = spec.to_dict()
+    ww = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
+    p = np.asarray(impl_out, dtype=np.float64)
+    if stage == "logits":
+        return p
+    first = 0 if stage == "features" else int(stage[4:])
+    for n in range(first, spec.rnn_layers):
+        p = nn_oracle.rnn_layer_forward(p, sl, sd, ww, n)
+    return nn_oracle.fc_head(p, ww)
+
+
 def greedy_report(logits_impl, logits64, sl, err_max):
     """chiron_eval.py:485-487 on both logits: identical windows, and every frame whose argmax differs with its float64 margin"""
     B = logits64.shape[0]
@@ -114,13 +129,13 @@ def greedy_report(logits_impl, logits64, sl, err_max):
             "smallest_margin": float(m.min()), "margin_quantiles": {q: float(np.quantile(m, float(q))) for q in ("0.001", "0.01", "0.1", "0.5")}}
 
 
-def budget(topology, n_windows, peaked, seed=67):
+def budget(topology, n_windows, peaked, seed=67, weight_seed=5):
     spec = ca.dna_default_spec() if topology == "dna" else ca.rna_default_spec()
     L, jump = (400, 390) if topology == "dna" else (500, 490)
     x, ln = windows(jump * (n_windows - 1) + 200, L, jump, seed)
     ln = ln.copy()
     ln[2], ln[5] = L // 3, 0
-    w, _ = regimes.trained_like_weights(spec, x[:24], seed=5)
+    w, _ = regimes.trained_like_weights(spec, x[:24], seed=weight_seed)
     if peaked:
         w = regimes.peaked_head(w)
     t0 = time.time()
@@ -130,7 +145,7 @@ def budget(topology, n_windows, peaked, seed=67):
     T = o64["logits"].shape[1]
     fmask = (np.arange(T)[None, :] < np.asarray(sl)[:, None])[..., None]
     order = ["features"] + ["lstm%d" % n for n in range(1, spec.rnn_layers + 1)] + ["logits"]
-    rep = {"topology": topology, "windows": int(x.shape[0]), "peaked_head": bool(peaked), "stages": {}}
+    rep = {"topology": topology, "windows": int(x.shape[0]), "peaked_head": bool(peaked), "signal_seed": seed, "weight_seed": weight_seed, "stages": {}}
     for impl_name, impl in (("engine", eng), ("numpy_fp32", n32)):
         prev = None
         for s in order:
@@ -139,6 +154,8 @@ def budget(topology, n_windows, peaked, seed=67):
             e[impl_name + "_total"] = stats(impl[s], o64[s], full)
             loc = local_reference(spec, w, s, prev, x, sl)
             e[impl_name + "_local"] = stats(impl[s], loc, full)
+            # what the stages up to and including s cost AT THE LOGITS (float64 oracle from here on)
+            e[impl_name + "_at_logits"] = stats(propagate_to_logits(spec, w, s, impl[s], sl), o64["logits"], np.broadcast_to(fmask, o64["logits"].shape))
             prev = impl[s]
     lg = rep["stages"]["logits"]
     rep["logits_ratio_engine_over_numpy_fp32"] = {k: lg["engine_total"][k] / max(lg["numpy_fp32_total"][k], 1e-30) for k in ("max", "rms")}
@@ -154,27 +171,37 @@ def budget(topology, n_windows, peaked, seed=67):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "default"
-    n = 24
-    if "--windows" in sys.argv:
-        n = int(sys.argv[sys.argv.index("--windows") + 1])
-        args = [a for a in args if a != str(n)]
-        tag = args[0] if args else "default"
-    peaked = "--peaked" in sys.argv
-    out = {"tag": tag, "lib": os.environ.get("CHIRON_AMD_LIB", "product"), "budgets": [budget(t, n, peaked) for t in ("dna", "rna")]}
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag", nargs="?", default="default")
+    ap.add_argument("--windows", type=int, default=24)
+    ap.add_argument("--peaked", action="store_true")
+    ap.add_argument("--weight-seeds", default="5", help="comma separated: one budget per topology and seed (the max-norm ratio of two "
+                    "amplified rounding errors is a noisy statistic; several weight sets show its spread)")
+    a = ap.parse_args()
+    tag, n, peaked = a.tag, a.windows, a.peaked
+    seeds = [int(v) for v in a.weight_seeds.split(",")]
+    out = {"tag": tag, "lib": os.environ.get("CHIRON_AMD_LIB") or "product",
+           "budgets": [budget(t, n, peaked, seed=67 + 10 * k, weight_seed=ws) for t in ("dna", "rna") for k, ws in enumerate(seeds)]}
+    if len(seeds) > 1:
+        out["ratio_engine_over_numpy_fp32_by_seed"] = {
+            t: {m: [b["logits_ratio_engine_over_numpy_fp32"][m] for b in out["budgets"] if b["topology"] == t] for m in ("max", "rms")}
+            for t in ("dna", "rna")}
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, "parity_budget_%s%s.json" % (tag, "_peaked" if peaked else ""))
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     for b in out["budgets"]:
-        print("== %s (%s%s): logits engine/numpy-fp32 max %.2f rms %.2f" % (b["topology"], tag, " peaked" if peaked else "",
+        print("== %s (%s%s, weights %d): logits engine/numpy-fp32 max %.2f rms %.2f" % (b["topology"], tag, " peaked" if peaked else "", b["weight_seed"],
               b["logits_ratio_engine_over_numpy_fp32"]["max"], b["logits_ratio_engine_over_numpy_fp32"]["rms"]))
         for s, e in b["stages"].items():
-            print("  %-9s scale %8.3g | engine total %.3g (rms %.3g) local %.3g (rms %.3g) | numpy-fp32 total %.3g (rms %.3g) local %.3g (rms %.3g)" % (
-                s, e["scale_rms"], e["engine_total"]["max"], e["engine_total"]["rms"], e["engine_local"]["max"], e["engine_local"]["rms"],
-                e["numpy_fp32_total"]["max"], e["numpy_fp32_total"]["rms"], e["numpy_fp32_local"]["max"], e["numpy_fp32_local"]["rms"]))
+            print("  %-9s scale %8.3g | engine total %.3g (rms %.3g) local %.3g (rms %.3g) at-logits %.3g (rms %.3g) | numpy-fp32 total %.3g (rms %.3g) "
+                  "local %.3g (rms %.3g) at-logits %.3g (rms %.3g)" % (
+                      s, e["scale_rms"], e["engine_total"]["max"], e["engine_total"]["rms"], e["engine_local"]["max"], e["engine_local"]["rms"],
+                      e["engine_at_logits"]["max"], e["engine_at_logits"]["rms"],
+                      e["numpy_fp32_total"]["max"], e["numpy_fp32_total"]["rms"], e["numpy_fp32_local"]["max"], e["numpy_fp32_local"]["rms"],
+                      e["numpy_fp32_at_logits"]["max"], e["numpy_fp32_at_logits"]["rms"]))
         g = b["greedy_engine_vs_float64"]
         print("  greedy: %d / %d windows identical, %d flipped frames (largest float64 margin %.3g, logit error %.3g)" % (
             g["identical_windows"], g["windows"], g["flipped_frames"], g["largest_margin_of_a_flipped_frame"], g["logit_error_max"]))
