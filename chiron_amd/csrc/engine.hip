@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -835,10 +836,17 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     if ((st = plan_sizes(desc, opts, &sz))) return st;   // argument checks and the 32-bit addressing limits, before any GPU call
   }
   if (desc->hidden != 100) return fail(CHIRON_ERR_INVALID, "hidden=%d: the recurrence kernel is built for hidden=100 (both shipped models)", desc->hidden);
+  // CHIRON_TRACE_CREATE=1: one line on stderr with where the time of this call went (tools/cold_start.py: the start-up budget of a
+  // rank of `chiron call`; at 1250 reads per GPU the compute is ~3 s, so start-up decides the end-to-end figure of configs[3])
+  const bool trace = getenv("CHIRON_TRACE_CREATE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_enter = now();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CHIRON_ERR_DEVICE, "no HIP device visible: libchiron_amd has no CPU fallback");
   if (opts->device_id < 0 || opts->device_id >= ndev) return fail(CHIRON_ERR_INVALID, "device_id %d out of range (%d devices)", opts->device_id, ndev);
   HIP_TRY(hipSetDevice(opts->device_id));
+  if (trace) HIP_TRY(hipFree(nullptr));     // forces the context (and the code objects of this library) onto the device now, so that the stage below is not charged for it
+  const double t_runtime = now();
 
   chiron_engine* e = new chiron_engine();
   e->desc = *desc;
@@ -883,12 +891,17 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     e->lstm16_fused = e->f16 && !e->lstm16_narrow && desc->hidden == 100 && (e->BP / 16) * 2 >= min_groups && getenv("CHIRON_LSTM16_UNFUSED") == nullptr;
   }
   st = build_plans(e, weights);
+  const double t_plans = now();
   if (st == CHIRON_OK) {
     e->slots.resize(e->opts.n_slots);
     for (Slot& s : e->slots)
       if ((st = alloc_slot(e, &s))) break;
   }
+  const double t_slots = now();
   if (st == CHIRON_OK && hipDeviceSynchronize() != hipSuccess) st = fail(CHIRON_ERR_DEVICE, "device sync after setup failed");
+  if (trace)
+    fprintf(stderr, "chiron_engine_create: {\"hip_runtime_and_context_ms\": %.1f, \"weights_prepared_and_uploaded_ms\": %.1f, \"slot_buffers_ms\": %.1f, "
+                    "\"final_sync_ms\": %.1f, \"slots\": %d}\n", t_runtime - t_enter, t_plans - t_runtime, t_slots - t_plans, now() - t_slots, e->opts.n_slots);
   if (st) {
     chiron_engine_destroy(e);
     return st;

@@ -39,6 +39,18 @@ def resolve_preset(args):
 
 def evaluation(args):
     """entry.py:19-47: extract fast5 -> <out>/raw, then basecall <out>/raw."""
+    import os as _os
+    n_gpus = int(getattr(args, "gpus", 0) or 0)
+    if n_gpus > 1 and not _os.environ.get("CHIRON_LOCAL_WORLD"):
+        # `chiron call --gpus N`: this process only starts the N ranks (one per GPU, each on its own slice of the host's cores)
+        # and waits; the ranks shard the reads, meet at a file barrier and rank 0 gathers merged.<ext> (shard.py)
+        from . import shard
+        resolve_preset(args)                       # a bad preset / mode fails here, once, not N times
+        _os.makedirs(args.output, exist_ok=True)
+        codes = shard.spawn_local_ranks(args.child_argv, n_gpus, args.output, share_gpu=_os.environ.get("CHIRON_SHARE_GPU") == "1")
+        if any(codes):
+            raise RuntimeError("chiron call --gpus %d: rank exit codes %s" % (n_gpus, codes))
+        return codes
     from . import eval as chiron_eval
     from .extract import extract
     args = resolve_preset(args)
@@ -117,6 +129,10 @@ def build_parser():
     p.add_argument("--test_number", default=None, type=int, help="Extract test_number reads, default all.")
     p.add_argument("-p", "--preset", default=None, help="Preset evaluation parameters: dna-pre, rna-pre")
     p.add_argument("--device", type=int, default=0, help="HIP device ordinal.")
+    p.add_argument("--gpus", type=int, default=0,
+                   help="Basecall on this many GPUs of the node: the command starts one process per GPU itself (reads sharded per "
+                        "process, host-side gather into merged.<ext>, per-process CPU affinity); 0 / 1: this process, --device.  "
+                        "(torch.distributed.run launches are honoured as before.)")
     p.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp32-split"],
                    help="Engine arithmetic: fp32 (parity path), fp16 (f16 MFMA conv + LSTM, fp32 CTC), fp32-split "
                         "(fp32 values as hi/lo half pairs on the f16 matrix cores).")
@@ -131,7 +147,9 @@ def build_parser():
 
 def main(arguments=None):
     parser = build_parser()
-    args = parser.parse_args(sys.argv[1:] if arguments is None else arguments)
+    argv = list(sys.argv[1:] if arguments is None else arguments)
+    args = parser.parse_args(argv)
+    args.child_argv = argv                    # `--gpus N` re-runs this command line in N rank processes
     if hasattr(args, "func"):
         return args.func(args)
     parser.print_help()

@@ -1530,6 +1530,12 @@ def test_sharded_call_equals_single_process(tmp_path):
     t0 = time.time()
     again = shard_run.run(wd, n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100, chunk=5, kind="fast5")
     assert again == rep5 and time.time() - t0 < 2.0
+    # the same with the ranks started by `chiron call --gpus 2` itself: no torch.distributed, a file barrier, per-rank CPU affinity
+    repl = shard_run.run(str(tmp_path / "c"), n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100, kind="fast5",
+                         launcher="local", keep=True)
+    assert repl["identical"] and repl["files_compared"] == 18 and repl["consensus_bases"] == rep["consensus_bases"]
+    ranks_dir = os.path.join(str(tmp_path / "c"), "chunk_000000", "out_2ranks", "log", "ranks")
+    assert sorted(os.listdir(ranks_dir)) == ["barrier.1.0", "barrier.1.1", "barrier.2.0", "barrier.2.1"]
 
 
 def test_device_consensus_equals_host_vote(tmp_path):

@@ -56,12 +56,17 @@ def write_model_dir(folder):
                    "rnn": {"layer_num": 3, "hidden_num": 100, "cell_type": "LSTM", "layer_type": "normal"}}, f)
 
 
-def call(inp, out, model, ranks, share_gpu, extension="fastq", batch=1100, port=29611, timeout=3600):
-    """`chiron call` (python -m chiron_amd.entry) on `ranks` processes; returns wall seconds."""
+def call(inp, out, model, ranks, share_gpu, extension="fastq", batch=1100, port=29611, timeout=3600, launcher="torchrun"):
+    """`chiron call` (python -m chiron_amd.entry) on `ranks` processes; returns wall seconds.  launcher "torchrun": the ranks are
+    started by torch.distributed.run (barriers over RCCL / gloo); "local": by `chiron call --gpus N` itself (file barrier, no torch)."""
     cmd = ["-m", "chiron_amd.entry", "call", "-i", inp, "-o", out, "-m", model, "--synthetic-weights", "-b", str(batch),
            "-l", "400", "-j", "390", "--beam", "0", "-e", extension, "-t", "4"]
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    if ranks > 1:
+    if ranks > 1 and launcher == "local":
+        cmd += ["--gpus", str(ranks)]
+        if share_gpu:
+            env["CHIRON_SHARE_GPU"] = "1"
+    elif ranks > 1:
         cmd = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks, "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + cmd
         env["MASTER_ADDR"] = "127.0.0.1"
@@ -89,7 +94,7 @@ def compare_trees(a, b, extension):
     return n
 
 
-def run_chunk(workdir, first, n_reads, n_samples, ranks, share_gpu, extension, batch, kind, keep):
+def run_chunk(workdir, first, n_reads, n_samples, ranks, share_gpu, extension, batch, kind, keep, launcher="torchrun"):
     """one chunk: inputs written, 1-rank and R-rank `chiron call`, trees compared, everything deleted again -> record"""
     import hashlib
     import shutil
@@ -103,7 +108,7 @@ def run_chunk(workdir, first, n_reads, n_samples, ranks, share_gpu, extension, b
     t1 = call(sig, out1, model, 1, False, extension, batch)
     merged1, n1 = shard.gather_results(out1, extension)          # a single process does not gather by itself
     shutil.rmtree(os.path.join(out1, "raw"), ignore_errors=True)   # the largest folder; never compared
-    tn = call(sig, outn, model, ranks, share_gpu, extension, batch)
+    tn = call(sig, outn, model, ranks, share_gpu, extension, batch, launcher=launcher)
     mergedn = os.path.join(outn, "merged." + extension)
     if n1 != n_reads:
         raise AssertionError("%d reads in, %d results out" % (n_reads, n1))
@@ -119,11 +124,12 @@ def run_chunk(workdir, first, n_reads, n_samples, ranks, share_gpu, extension, b
     return rec
 
 
-def run(workdir, n_reads, n_samples, ranks, share_gpu, extension="fastq", batch=1100, chunk=0, kind="signal", keep=False):
+def run(workdir, n_reads, n_samples, ranks, share_gpu, extension="fastq", batch=1100, chunk=0, kind="signal", keep=False, launcher="torchrun"):
     os.makedirs(workdir, exist_ok=True)
     chunk = chunk if chunk > 0 else n_reads
     state_path = os.path.join(workdir, "state.json")
-    key = {"reads": n_reads, "samples_per_read": n_samples, "ranks": ranks, "extension": extension, "batch": batch, "chunk": chunk, "input": kind}
+    key = {"reads": n_reads, "samples_per_read": n_samples, "ranks": ranks, "extension": extension, "batch": batch, "chunk": chunk, "input": kind,
+           "launcher": launcher}
     state = {"key": key, "chunks": {}}
     if os.path.exists(state_path):
         old = json.load(open(state_path))
@@ -132,13 +138,14 @@ def run(workdir, n_reads, n_samples, ranks, share_gpu, extension="fastq", batch=
     for first in range(0, n_reads, chunk):
         if str(first) in state["chunks"]:
             continue
-        state["chunks"][str(first)] = run_chunk(workdir, first, min(chunk, n_reads - first), n_samples, ranks, share_gpu, extension, batch, kind, keep)
+        state["chunks"][str(first)] = run_chunk(workdir, first, min(chunk, n_reads - first), n_samples, ranks, share_gpu, extension, batch, kind, keep, launcher)
         tmp = state_path + ".tmp"
         with open(tmp, "w") as f:
             json.dump(state, f, indent=1, sort_keys=True)
         os.replace(tmp, state_path)
     recs = [state["chunks"][k] for k in sorted(state["chunks"], key=int)]
-    return {"reads": n_reads, "samples_per_read": n_samples, "ranks": ranks, "share_gpu": bool(share_gpu), "input": kind, "chunks": len(recs),
+    return {"reads": n_reads, "samples_per_read": n_samples, "ranks": ranks, "share_gpu": bool(share_gpu), "input": kind, "launcher": launcher,
+            "chunks": len(recs),
             "files_compared": sum(r["files_compared"] for r in recs), "merged_bytes": sum(r["merged_bytes"] for r in recs),
             "consensus_bases": sum(r["consensus_bases"] for r in recs), "identical": True,
             "wall_s_1rank": round(sum(r["wall_s_1rank"] for r in recs), 2), "wall_s_%dranks" % ranks: round(sum(r["wall_s_ranks"] for r in recs), 2)}
@@ -156,10 +163,12 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="reads per chunk (0: all at once); the disk holds one chunk at a time")
     ap.add_argument("--input", default="signal", choices=["signal", "fast5"], help="input files: .signal text or fast5 (direct path)")
     ap.add_argument("--keep", action="store_true", help="keep the chunk folders (inputs and both output trees)")
+    ap.add_argument("--launcher", default="torchrun", choices=["torchrun", "local"],
+                    help="who starts the ranks: torch.distributed.run, or `chiron call --gpus N` itself (file barrier, no torch)")
     a = ap.parse_args()
     import tempfile
     wd = a.workdir or tempfile.mkdtemp(prefix="chiron_shard_")
-    print(json.dumps(run(wd, a.reads, a.samples, a.ranks, a.share_gpu, a.extension, a.batch, a.chunk, a.input, a.keep)))
+    print(json.dumps(run(wd, a.reads, a.samples, a.ranks, a.share_gpu, a.extension, a.batch, a.chunk, a.input, a.keep, a.launcher)))
 
 
 if __name__ == "__main__":
