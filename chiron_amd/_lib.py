@@ -75,6 +75,7 @@ SYMBOLS = [
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("chiron_engine_features", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("chiron_engine_rnn_output", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("chiron_engine_calibrate", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("chiron_engine_profile", C.c_int, [C.c_void_p, C.c_int32]),
     ("chiron_engine_profile_read", C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
     ("chiron_parse_signal_text", C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -102,6 +102,25 @@ __global__ __launch_bounds__(256) void rank1_conv_kernel(const float* __restrict
   }
 }
 
+// Column sums of a channels-last activation tensor of HALVES (the f16 engine's calibration pass, engine.hip: chiron_engine_calibrate):
+// sums[c] += sum over rows m of x[m * ld + col0 + c], c < cin; rows of a time-major tensor (m = t * BP + b) count only for b < B.
+__global__ __launch_bounds__(256) void colsum_f16_kernel(const _Float16* __restrict__ x, long rows, int ld, int col0, int cin, int BP, int B,
+                                                         double* __restrict__ sums) {
+  const int c = threadIdx.x;
+  if (c >= cin) return;
+  double a = 0;
+  const long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long m0 = (long)blockIdx.x * per, m1 = m0 + per < rows ? m0 + per : rows;
+  for (long m = m0; m < m1; ++m) {
+    if (BP > 0 && (int)(m % BP) >= B) continue;
+    a += (double)(float)x[m * ld + col0 + c];
+  }
+  atomicAdd(&sums[c], a);
+}
+void launch_colsum_f16(const void* x, long rows, int ld, int col0, int cin, int BP, int B, double* sums, hipStream_t stream) {
+  hipLaunchKernelGGL(colsum_f16_kernel, dim3(512), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(x), rows, ld, col0, cin, BP, B, sums);
+}
+
 void launch_bn_stats(const float* x, long M, int C, double* sums, hipStream_t stream) {
   hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), stream);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(1024), dim3(256), 0, stream, x, M, C, sums);

@@ -144,6 +144,27 @@ struct ConvGemmPlan {
   int N = 0, Npad = 0, K = 0;
 };
 
+// f16 engine, calibration (chiron_engine_calibrate): what a plan's weights lost when they were rounded to halves.
+// y[n] = sum_k x[k] f16(W[n][k]) = sum_k x[k] W[n][k] + sum_k x[k] dW[n][k]; the second sum's MEAN over the data, sum_k E[x_k] dW[n][k],
+// is a constant per output channel and is taken out of the plan's shift once the input channels' means are known.
+struct PlanHost {
+  std::vector<float> dW;       // [Npad][K]: (float)(_Float16)W - W of the BN-folded fp32 weight (0 in the K / N padding)
+  std::vector<float> shift0;   // the uncorrected shift
+  int N = 0, Npad = 0, K = 0;
+};
+struct CalibRecord {           // one measured input: columns [k0, k0 + cin) of the plan behind `shift`, or rows of an LSTM kernel
+  const float* shift;          // device shift array of the plan (key into plan_host), or the projection's for an LSTM layer
+  int k0, cin;
+  int lstm_layer, lstm_dir, lstm_part;   // lstm_layer >= 0: part 0 = x rows [k0, k0 + cin) of the TF kernel, part 1 = its h rows; dir -1 = both
+  double rows;                 // rows summed
+  size_t slot;                 // index of the record's [256] doubles in the device sum buffer
+};
+struct CalibCtx {
+  double* dev_sums = nullptr;  // [max_records][256]
+  size_t max_records = 0;
+  std::vector<CalibRecord> rec;
+};
+
 struct BlockPlan {
   bool lift = false;
   int c_in = 0, c = 0, k = 0, stride = 1, left = 0;
@@ -263,6 +284,11 @@ struct chiron_engine {
   std::vector<LstmPlan> lstm;
   float *fc_w = nullptr, *fc_b = nullptr, *fc_wc = nullptr, *fc_bc = nullptr;
   std::vector<Slot> slots;
+  std::map<const float*, PlanHost> plan_host;   // f16 engine: keyed by the plan's device shift pointer
+  std::vector<float> host_weights;              // f16 engine: the caller's blob (LSTM kernels are read back from it in calibration)
+  std::vector<size_t> lstm_kernel_off[2];       // offset of layer l's kernel of direction d in host_weights
+  CalibCtx* calib = nullptr;                    // non-null while chiron_engine_calibrate runs the network
+  int calibrated = 0;                           // iterations applied so far
   std::vector<void*> owned;  // device allocations freed on destroy
   bool profiling = false;
   std::vector<std::string> prof_names;
@@ -323,6 +349,13 @@ static chiron_status upload_gemm(chiron_engine* e, ConvGemmPlan* g, const std::v
     _Float16* d = nullptr;
     if ((st = dev_upload(e, &d, h))) return st;
     g->Wt = reinterpret_cast<float*>(d);
+    if ((st = dev_upload(e, &g->shift, shift))) return st;
+    PlanHost& ph = e->plan_host[g->shift];
+    ph.dW.resize(Wt.size());
+    for (size_t i = 0; i < Wt.size(); ++i) ph.dW[i] = (float)h[i] - Wt[i];
+    ph.shift0 = shift;
+    ph.N = N, ph.Npad = Npad, ph.K = K;
+    return CHIRON_OK;
   } else if ((st = dev_upload(e, &g->Wt, Wt))) {
     return st;
   }
@@ -573,6 +606,7 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
     const float* bias[2];
     for (int dir = 0; dir < 2; ++dir) {
       kern[dir] = p;
+      e->lstm_kernel_off[dir].push_back((size_t)(p - w));
       p += (size_t)(lp.in_w + H) * 4 * H;
       bias[dir] = p;
       p += 4 * H;
@@ -890,6 +924,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     const int min_groups = getenv("CHIRON_LSTM16_FUSED_MIN") ? atoi(getenv("CHIRON_LSTM16_FUSED_MIN")) : 64;
     e->lstm16_fused = e->f16 && !e->lstm16_narrow && desc->hidden == 100 && (e->BP / 16) * 2 >= min_groups && getenv("CHIRON_LSTM16_UNFUSED") == nullptr;
   }
+  if (e->f16) e->host_weights.assign(weights, weights + n_floats);
   st = build_plans(e, weights);
   const double t_plans = now();
   if (st == CHIRON_OK) {
@@ -974,7 +1009,25 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
 }
 
 // Segments are filled in ELEMENTS; the f16 kernels address in 4-byte units (see GemmParams::f16).
+// Calibration pass of the f16 engine: before a convolution GEMM runs, the column sums of every K-segment's source.
+static void calib_measure(chiron_engine* e, const float* shift, int k0, const void* src, long rows, int ld, int col0, int cin, int BP, int B,
+                          int lstm_layer, int lstm_dir, int lstm_part, hipStream_t stream) {
+  CalibCtx* c = e->calib;
+  if (!c || c->rec.size() >= c->max_records || cin > 256) return;
+  CalibRecord r{shift, k0, cin, lstm_layer, lstm_dir, lstm_part, BP > 0 ? (double)(rows / BP) * B : (double)rows, c->rec.size()};
+  launch_colsum_f16(src, rows, ld, col0, cin, BP, B, c->dev_sums + r.slot * 256, stream);
+  c->rec.push_back(r);
+}
+
 static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
+  if (e->calib && e->f16 && g.out_mode == 0) {       // (the LSTM projections are measured in run_rnn, fused or not)
+    int k0 = 0;
+    for (int i = 0; i < g.nseg; ++i) {
+      const GemmSeg& sg = g.seg[i];
+      if (sg.src) calib_measure(e, g.shift, k0, sg.src, (long)g.B * sg.w_in, sg.lda, sg.col0, sg.cin, 0, g.B, -1, 0, 0, stream);
+      k0 += sg.kpad;
+    }
+  }
   Slot* own = nullptr;   // the slot this stream belongs to: its tile counters (dynamic tile scheduling)
   if (e->dyn_tiles)
     for (Slot& sl : e->slots)
@@ -1292,11 +1345,24 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.fixed_roles = e->lstm_fixed_roles ? 1 : 0;
     r.group0 = 0;
     r.f16 = e->f16 ? 1 : 0;
+    if (e->calib && e->f16) {
+      // x rows of the layer's kernels: the means of the layer's input (features: batch-major rows; lasth: time-major)
+      for (int pj = 0; pj < lp.nproj; ++pj) {
+        const int dir = lp.nproj == 1 ? -1 : pj;
+        if (l == 0)
+          calib_measure(e, lp.proj[pj].shift, 0, fea, (long)B * T, e->C, 0, e->C, 0, B, (int)l, dir, 0, s->stream);
+        else
+          calib_measure(e, lp.proj[pj].shift, 0, prev, (long)T * BP, e->lasth_ld, lp.nproj == 1 ? 0 : pj * H, lp.in_w, BP, B, (int)l, dir, 0, s->stream);
+      }
+    }
     {
       Prof pr(e, s, PN_REC, 2.0 * 2.0 * B * T * (double)H * 4 * H + (fused ? 2.0 * B * T * (double)lp.in_w * 4 * H * 2.0 : 0.0),
               fused ? (e->f16 ? 2.0 : 4.0) * B * T * (2.0 * lp.in_w + 2.0 * H) : 4.0 * B * T * 2.0 * (zc + H));
       launch_lstm(r, s->stream);
     }
+    if (e->calib && e->f16)      // h rows: the means of the layer's own output, per direction
+      for (int dir = 0; dir < 2; ++dir)
+        calib_measure(e, lp.proj[lp.nproj == 1 ? 0 : dir].shift, 0, outbuf, (long)T * BP, e->lasth_ld, dir * H, H, BP, B, (int)l, dir, 1, s->stream);
     prev = outbuf;
     if (e->split) {
       if (l + 1 < e->lstm.size()) {
@@ -1566,6 +1632,109 @@ extern "C" chiron_status chiron_engine_features(chiron_engine* e, int32_t slot, 
     HIP_TRY(hipMemcpy(out, s->sig_used, n * 4, hipMemcpyDeviceToHost));
   }
   return CHIRON_OK;
+}
+
+// Bias correction of the f16 engine (post-training-quantisation style, data dependent only through per-channel MEANS of a
+// calibration batch): run the network, measure the mean of every input channel of every f16 weight matrix, move
+// sum_k E[x_k] (f16(W) - W)[n][k] out of the shift / LSTM bias of output n.  Upstream corrections move downstream means a little,
+// hence `iterations` (2 is enough).  tools/f16_study.py: on trained-checkpoint-like weights the mean term is most of what rounding
+// the weights to halves costs.
+extern "C" chiron_status chiron_engine_calibrate(chiron_engine* e, const float* x, const int32_t* seq_len, int32_t batch, int32_t iterations) {
+  if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
+  if (!x || !seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
+  if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
+  if (iterations < 0 || iterations > 16) return fail(CHIRON_ERR_INVALID, "iterations %d", iterations);
+  if (!e->f16) return CHIRON_OK;      // fp32 / fp32-split weights are not rounded: nothing to correct
+  Slot* s = &e->slots[0];
+  for (Slot& sl : e->slots)
+    if (sl.state.v.load(std::memory_order_acquire) != 0) return fail(CHIRON_ERR_STATE, "chiron_engine_calibrate needs every slot idle");
+  HIP_TRY(hipSetDevice(e->opts.device_id));
+  const int B = batch, H = e->H;
+  CalibCtx ctx;
+  ctx.max_records = 256;
+  HIP_TRY(hipMalloc((void**)&ctx.dev_sums, ctx.max_records * 256 * sizeof(double)));
+  chiron_status st = CHIRON_OK;
+  std::vector<double> sums(ctx.max_records * 256);
+  for (int it = 0; it < iterations && st == CHIRON_OK; ++it) {
+    ctx.rec.clear();
+    auto run = [&]() -> chiron_status {
+      HIP_TRY(hipMemsetAsync(ctx.dev_sums, 0, ctx.max_records * 256 * sizeof(double), s->stream));
+      HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
+      memcpy(s->h_sig, x, (size_t)B * e->L * 4);
+      memcpy(s->h_seq, seq_len, (size_t)B * 4);
+      HIP_TRY(hipMemcpyAsync(s->sig, s->h_sig, (size_t)B * e->L * 4, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(s->seq, s->h_seq, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
+      e->calib = &ctx;
+      const bool ok = run_cnn(e, s, B, s->sig) && run_rnn(e, s, B);
+      e->calib = nullptr;
+      if (!ok) return fail(CHIRON_ERR_INVALID, "a GEMM of this topology has no kernel for the engine's dtype");
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      HIP_TRY(hipMemcpy(sums.data(), ctx.dev_sums, ctx.rec.size() * 256 * sizeof(double), hipMemcpyDeviceToHost));
+      return CHIRON_OK;
+    };
+    st = run();
+    s->net_batch = 0;
+    if (st) {
+      resync_tile_counters(s);
+      break;
+    }
+    // corrections, always from the ORIGINAL shifts: correction[n] = - sum over the records of the plan of sum_c mean[c] * dW[n][k0 + c]
+    std::map<const float*, std::vector<double>> corr;
+    const int parts = getenv("CHIRON_CALIB_PARTS") ? atoi(getenv("CHIRON_CALIB_PARTS")) : 7;   // diagnostics: 1 convolutions, 2 LSTM x rows, 4 LSTM h rows
+    for (const CalibRecord& r : ctx.rec) {
+      auto ph = e->plan_host.find(r.shift);
+      if (ph == e->plan_host.end() || r.rows <= 0) continue;
+      if (!(parts & (r.lstm_layer < 0 ? 1 : r.lstm_part == 0 ? 2 : 4))) continue;
+      std::vector<double>& c = corr[r.shift];
+      c.resize(ph->second.Npad, 0.0);
+      const double* sm = &sums[r.slot * 256];
+      if (r.lstm_layer < 0) {
+        const PlanHost& P = ph->second;
+        for (int n = 0; n < P.N; ++n) {
+          double a = 0;
+          for (int k = 0; k < r.cin; ++k) a += sm[k] * (double)P.dW[(size_t)n * P.K + r.k0 + k];
+          c[n] -= a / r.rows;
+        }
+      } else {
+        // rows of the TF kernel [(in_w + H)][4H] of layer l, direction d: x rows (part 0) or h rows (part 1); output column n of the
+        // plan = dir * 4H + gate * H + unit (one direction per plan in the MultiRNN layers above 0)
+        const LstmPlan& lp = e->lstm[r.lstm_layer];
+        const int zc = 4 * H;
+        for (int dir = 0; dir < 2; ++dir) {
+          if (r.lstm_dir >= 0 && dir != r.lstm_dir) continue;
+          const float* kern = e->host_weights.data() + e->lstm_kernel_off[dir][r.lstm_layer];
+          const int row0 = r.lstm_part == 0 ? 0 : lp.in_w;
+          const int nbase = lp.nproj == 1 ? dir * zc : 0;
+          for (int col = 0; col < zc; ++col) {
+            double a = 0;
+            for (int k = 0; k < r.cin; ++k) {
+              const float wv = kern[(size_t)(row0 + k) * zc + col];
+              a += sm[k] * ((double)(float)(_Float16)wv - (double)wv);
+            }
+            c[nbase + col] -= a / r.rows;
+          }
+        }
+      }
+    }
+    for (auto& kv : corr) {
+      const PlanHost& P = e->plan_host[kv.first];
+      std::vector<float> sh(P.shift0);
+      for (int n = 0; n < P.Npad; ++n) sh[n] = (float)((double)P.shift0[n] + kv.second[n]);
+      if (hipMemcpy(const_cast<float*>(kv.first), sh.data(), sh.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        st = fail(CHIRON_ERR_DEVICE, "uploading a corrected shift failed");
+        break;
+      }
+    }
+    if (st == CHIRON_OK) e->calibrated = it + 1;
+  }
+  if (iterations == 0) {   // back to the uncorrected engine
+    for (auto& kv : e->plan_host)
+      if (hipMemcpy(const_cast<float*>(kv.first), kv.second.shift0.data(), kv.second.shift0.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        st = fail(CHIRON_ERR_DEVICE, "restoring a shift failed");
+    e->calibrated = 0;
+  }
+  hipFree(ctx.dev_sums);
+  return st;
 }
 
 // The recurrent stack's output (rnn.py:63-65 / :140-145, the tensor the FC head of rnn.py:72-96 reads), re-ordered from the

@@ -256,6 +256,8 @@ void launch_path_prob(const PathProbParams& p, hipStream_t stream);
 // batch-statistics BatchNorm (bn_batch.hip): cnn.py:166-188 simple_global_bn
 // ---------------------------------------------------------------------------------------------
 void launch_bn_stats(const float* x, long M, int C, double* sums /* [2][C] */, hipStream_t stream);
+// sums[c] += sum_m x[m * ld + col0 + c] over `rows` rows of halves (BP > 0: time-major rows m = t * BP + b, only b < B count)
+void launch_colsum_f16(const void* x, long rows, int ld, int col0, int cin, int BP, int B, double* sums /* [cin], zeroed by the caller */, hipStream_t stream);
 void launch_bn_apply(float* x, const double* sums, const float* scale, const float* offset, long M, int C, int relu, const float* add,
                      const double* add_sums, const float* add_scale, const float* add_offset, hipStream_t stream);
 void launch_rank1_conv(const float* sig, const float* w, float* out, long n_pos, int T_out, int L, int stride, int C, hipStream_t stream);

@@ -158,6 +158,19 @@ class Engine(object):
         _lib.check(self._lib.chiron_engine_features(self._h, slot, out.ctypes.data_as(C.c_void_p), out.size, C.byref(b), C.byref(c)))
         return out
 
+    def calibrate(self, x=None, seq_len=None, iterations=2):
+        """f16 engines: bias correction for the weights' rounding to halves (chiron_engine_calibrate); a no-op for fp32 / fp32-split.
+        x [n, segment_len] float32 calibration windows (default: `calibration_windows`, a fixed synthetic squiggle, so that every
+        process that builds this engine builds the same one); iterations = 0 restores the uncorrected engine."""
+        if x is None:
+            x, seq_len = calibration_windows(self.segment_len, min(self.max_batch, 256), self.ratio)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
+        if x.ndim != 2 or x.shape[1] != self.segment_len or seq_len.shape[0] != x.shape[0]:
+            raise ValueError("x must be [n, %d] with one seq_len per row" % self.segment_len)
+        _lib.check(self._lib.chiron_engine_calibrate(self._h, x.ctypes.data_as(C.c_void_p), seq_len.ctypes.data_as(C.c_void_p),
+                                                     x.shape[0], int(iterations)))
+
     def rnn_output(self, slot=0):
         """`lasth` (rnn.py:63-65 / :140-145): the recurrent stack's output [batch, T, 2H] of the batch last run on the (idle) slot."""
         b, w = C.c_int32(), C.c_int32()
@@ -189,6 +202,15 @@ class Engine(object):
             s = arr[i]
             out[s.name.decode()] = {"total_ms": s.total_ms, "launches": s.launches, "flops": s.flops, "bytes": s.bytes}
         return out
+
+
+def calibration_windows(segment_len, n, ratio, seed=20260928):
+    """The fixed calibration batch of `chiron call --dtype fp16`: n full windows of a seeded synthetic 4 kHz squiggle (model.
+    synthetic_signal: dwell ~ 8.9 samples per level, levels N(500, 80) clipped to [200, 1000]) -> (x, seq_len)."""
+    from .model import synthetic_signal
+    sig = synthetic_signal(1, segment_len * n, seed=seed)[0]
+    x = np.ascontiguousarray(sig[:segment_len * n].reshape(n, segment_len), dtype=np.float32)
+    return x, seq_len_for_engine(np.full(n, segment_len), ratio)
 
 
 def seq_len_for_engine(lengths, ratio):

@@ -136,6 +136,9 @@ def build_parser():
     p.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp32-split"],
                    help="Engine arithmetic: fp32 (parity path), fp16 (f16 MFMA conv + LSTM, fp32 CTC), fp32-split "
                         "(fp32 values as hi/lo half pairs on the f16 matrix cores).")
+    p.add_argument("--no-calibration", dest="no_calibration", action="store_true",
+                   help="--dtype fp16: skip the bias correction for the weights' rounding to halves (Engine.calibrate on a fixed synthetic "
+                        "calibration batch at start-up).")
     p.add_argument("--via-signal-files", dest="via_signal_files", action="store_true",
                    help="fast5 input: the reference's two passes (extract everything to raw/*.signal, then parse the text back) "
                         "instead of windowing the decoded samples directly; same output files.")

@@ -436,6 +436,10 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
         engine = Engine(spec, weights, max_batch=FLAGS.batch_size, segment_len=FLAGS.segment_len,
                         device_id=getattr(FLAGS, "device", 0), n_slots=int(getattr(FLAGS, "slots", 0) or 3), max_beam=FLAGS.beam,
                         dtype=getattr(FLAGS, "dtype", "fp32"))
+        if getattr(FLAGS, "dtype", "fp32") == "fp16" and not getattr(FLAGS, "no_calibration", False):
+            # bias correction for the weights' rounding to halves (Engine.calibrate): a fixed synthetic calibration batch, so every
+            # rank of a sharded run builds the same engine and a read's output does not depend on which process basecalls it
+            engine.calibrate()
     if fast5_files is None:
         files, file_dir = list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
         if file_list is not None:

@@ -212,6 +212,17 @@ chiron_status chiron_engine_features(chiron_engine* e, int32_t slot, float* out,
 chiron_status chiron_engine_rnn_output(chiron_engine* e, int32_t slot, float* out, size_t cap_floats, int32_t* out_batch,
                                        int32_t* out_width);
 
+/* f16 engines only (CHIRON_F16; a no-op returning CHIRON_OK for the other dtypes): bias correction for the weights' rounding to
+ * halves.  The reference has no counterpart (it computes in fp32); this is what lets the f16 engine be used on a trained checkpoint
+ * whose BN sites cancel large convolution means (tools/f16_study.py: there most of what half-precision WEIGHTS cost is a constant
+ * per output channel, sum_k E[x_k] (f16(W) - W)[n][k]).  The call runs `batch` calibration windows (same x / seq_len convention as
+ * chiron_engine_submit, host pointers) through the network `iterations` times (2 is enough; upstream corrections move downstream
+ * means slightly), measures the mean of every input channel of every f16 weight matrix -- convolutions, LSTM input and recurrent
+ * kernels -- and moves that constant out of the folded BN shift / LSTM bias.  No run-time cost afterwards.  Every slot must be idle.
+ * iterations = 0 restores the uncorrected shifts.  The correction depends on the calibration windows through per-channel MEANS
+ * only; `chiron call --dtype fp16` calibrates on a fixed synthetic squiggle, so every rank of a sharded run holds the same engine. */
+chiron_status chiron_engine_calibrate(chiron_engine* e, const float* x, const int32_t* seq_len, int32_t batch, int32_t iterations);
+
 /* Per-kernel timing with HIP events on the engine's own streams (bench.py
  * roofline).  Enable, run, sync, then read.                                    */
 typedef struct {
