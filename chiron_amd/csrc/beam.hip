@@ -331,6 +331,27 @@ __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Rank of a leaf = number of leaves that sort before it (larger total, or equal total and lower slot).  The totals of the live
+// quads lie in the LDS (entries past the leaves hold -inf and count for nobody).  The read of quad q + 1 is issued before quad q is
+// compared: the plain loop paid one LDS round trip per iteration (8 x ~100 cycles per frame at W = 30).  (All reads up front in a
+// register array is what one would write first; it took the kernels from 81 / 95 to 216 / 140 registers, and between the other
+// batches' GEMM waves the decoder's register footprint decides where its waves fit: +0.6 ms per batch in the mix.)
+__device__ __forceinline__ int rank_in_block(const int* totals, int nq, float mine, int slot) {
+  int r = 0;
+  int4 nx = *reinterpret_cast<const int4*>(totals);
+  for (int q = 0; q < nq; ++q) {
+    const int4 t4 = nx;
+    if (q + 1 < nq) nx = *reinterpret_cast<const int4*>(totals + 4 * (q + 1));   // nq is wave-uniform
+    const float tk0 = __int_as_float(t4.x), tk1 = __int_as_float(t4.y), tk2 = __int_as_float(t4.z), tk3 = __int_as_float(t4.w);
+    const int k0 = 4 * q;
+    r += (tk0 > mine) || (tk0 == mine && k0 < slot);
+    r += (tk1 > mine) || (tk1 == mine && k0 + 1 < slot);
+    r += (tk2 > mine) || (tk2 == mine && k0 + 2 < slot);
+    r += (tk3 > mine) || (tk3 == mine && k0 + 3 < slot);
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node_cap) {
   __shared__ __attribute__((aligned(16))) int scratch[B64_FIELDS * 64];   // permutation buffer: [field][rank]
   __shared__ __attribute__((aligned(16))) int chupd[64 * 4];              // [branch slot][label] node id of the child materialised this frame
@@ -457,12 +478,12 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         const int c = rli(evc, i);
         const bool ins = (rli((int)cnd, i) >> c) & 1;
         if (ins) {
+          // Only the new leaf's TOTAL is needed inside the walk (it decides the next bottom).  Its node id, parent node and depth
+          // are facts about the branch (i, c) that spawned it and are fetched ONCE per frame, after the walk, by the lane that
+          // still owns the leaf then (l_pi, l_lc): three broadcasts per event used to carry them, although a slot may be
+          // overwritten again within the frame.
           const float sel_tot = c == 0 ? cand[0] : c == 1 ? cand[1] : c == 2 ? cand[2] : cand[3];   // c is wave-uniform
-          const int sel_node = c == 0 ? e_ch[0] : c == 1 ? e_ch[1] : c == 2 ? e_ch[2] : e_ch[3];
           const float tot = rlf(sel_tot, i);
-          const int node = rli(sel_node, i);
-          const int pnode = rli(e_node, i);
-          const int depth = rli(e_depth, i) + 1;
           int slot;
           if (full) {  // the bottom leaves the search
             slot = boti;
@@ -479,10 +500,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
             l_tot = tot;
             l_blk = NEG_INF;
             l_lab = tot;
-            l_node = node;
-            l_par = pnode;
             l_lc = c;
-            l_depth = depth;
             l_orig = -1;
             l_pi = i;
           }
@@ -512,6 +530,17 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
       csu[lane] = 0u;
       csr[lane] = 0u;
       const bool isleaf = lane < nL;
+      {   // the inserted leaves fetch what their branch knows about them (see the walk): six shuffles per frame
+        const bool got = isleaf && l_pi >= 0;
+        const int src = got ? l_pi : lane;
+        const int g_node = __shfl(e_node, src), g_depth = __shfl(e_depth, src);
+        const int g0 = __shfl(e_ch[0], src), g1 = __shfl(e_ch[1], src), g2 = __shfl(e_ch[2], src), g3 = __shfl(e_ch[3], src);
+        if (got) {
+          l_par = g_node;
+          l_depth = g_depth + 1;
+          l_node = l_lc == 0 ? g0 : l_lc == 1 ? g1 : l_lc == 2 ? g2 : g3;
+        }
+      }
       const bool inserted = isleaf && l_par >= 0;     // otherwise a leaf is this lane's carried entry (an evicted one's slot holds an inserted child)
       const bool fresh = inserted && l_node < 0;
       const bool reins = inserted && !fresh;
@@ -562,19 +591,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
       // broadcast read: a v_readlane per leaf cost 93 cycles each, 2800 of the 4200 cycles P3 took per frame at W = 30.
       scratch[lane] = __float_as_int(lane < nL ? l_tot : NEG_INF);
       lds_sync();
-      int r = 0;
-      {
-        const int nq = (nL + 3) >> 2;   // wave-uniform
-        for (int q4 = 0; q4 < nq; ++q4) {
-          const int4 t4 = *reinterpret_cast<const int4*>(scratch + 4 * q4);
-          const float tk0 = __int_as_float(t4.x), tk1 = __int_as_float(t4.y), tk2 = __int_as_float(t4.z), tk3 = __int_as_float(t4.w);
-          const int k0 = 4 * q4;
-          r += (tk0 > l_tot) || (tk0 == l_tot && k0 < lane);
-          r += (tk1 > l_tot) || (tk1 == l_tot && k0 + 1 < lane);
-          r += (tk2 > l_tot) || (tk2 == l_tot && k0 + 2 < lane);
-          r += (tk3 > l_tot) || (tk3 == l_tot && k0 + 3 < lane);
-        }
-      }
+      const int r = rank_in_block(scratch, (nL + 3) >> 2, l_tot, lane);
       // Slot references into the next beam (all encoded + 1, 0 = not in the beam).  A carried entry that is still a leaf
       // publishes its rank under its old slot; whoever referred to that slot follows it, whoever referred to a slot whose
       // entry left the beam reads 0.  A surviving new child reports its rank to the branch that spawned it.
@@ -817,12 +834,8 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
         const bool ins = hev && ((__shfl((int)cnd, src) >> c) & 1);
         const bool rs = hev && !ins;
         const float sel_tot = c == 0 ? cand[0] : c == 1 ? cand[1] : c == 2 ? cand[2] : cand[3];
-        const int sel_node = c == 0 ? e_ch[0] : c == 1 ? e_ch[1] : c == 2 ? e_ch[2] : e_ch[3];
         const int sel_co = c == 0 ? chs[0] : c == 1 ? chs[1] : c == 2 ? chs[2] : chs[3];
-        const float tot = __shfl(sel_tot, src);
-        const int node = __shfl(sel_node, src);
-        const int pnode = __shfl(e_node, src);
-        const int depth = __shfl(e_depth, src) + 1;
+        const float tot = __shfl(sel_tot, src);     // node id, parent node and depth of a new leaf: once per frame, after the walk (beam64_kernel)
         const int co = __shfl(sel_co, src);
         // insertion: the bottom leaves the search (full) or the leaves grow by one
         const int slot = full ? boti : nL;
@@ -837,10 +850,7 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
           l_tot = tot;
           l_blk = NEG_INF;
           l_lab = tot;
-          l_node = node;
-          l_par = pnode;
           l_lc = c;
-          l_depth = depth;
           l_orig = -1;
           l_pi = i;
         }
@@ -868,6 +878,17 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
       csu[lane] = 0u;
       csr[lane] = 0u;
       const bool isleaf = hl < nL;
+      {
+        const bool got = isleaf && l_pi >= 0;
+        const int src = got ? hb + l_pi : lane;
+        const int g_node = __shfl(e_node, src), g_depth = __shfl(e_depth, src);
+        const int g0 = __shfl(e_ch[0], src), g1 = __shfl(e_ch[1], src), g2 = __shfl(e_ch[2], src), g3 = __shfl(e_ch[3], src);
+        if (got) {
+          l_par = g_node;
+          l_depth = g_depth + 1;
+          l_node = l_lc == 0 ? g0 : l_lc == 1 ? g1 : l_lc == 2 ? g2 : g3;
+        }
+      }
       const bool inserted = isleaf && l_par >= 0;
       const bool fresh = inserted && l_node < 0;
       const bool reins = inserted && !fresh;
@@ -912,19 +933,7 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
       }
       scratch[lane] = __float_as_int(isleaf ? l_tot : NEG_INF);
       lds_sync();
-      int r = 0;
-      {
-        const int nq = (max(rli(nL, 0), rli(nL, 32)) + 3) >> 2;   // wave-uniform; a half's entries past its own leaves hold -inf
-        for (int q4 = 0; q4 < nq; ++q4) {
-          const int4 t4 = *reinterpret_cast<const int4*>(scratch + hb + 4 * q4);
-          const float tk0 = __int_as_float(t4.x), tk1 = __int_as_float(t4.y), tk2 = __int_as_float(t4.z), tk3 = __int_as_float(t4.w);
-          const int k0 = 4 * q4;
-          r += (tk0 > l_tot) || (tk0 == l_tot && k0 < hl);
-          r += (tk1 > l_tot) || (tk1 == l_tot && k0 + 1 < hl);
-          r += (tk2 > l_tot) || (tk2 == l_tot && k0 + 2 < hl);
-          r += (tk3 > l_tot) || (tk3 == l_tot && k0 + 3 < hl);
-        }
-      }
+      const int r = rank_in_block(scratch + hb, (max(rli(nL, 0), rli(nL, 32)) + 3) >> 2, l_tot, hl);   // a half's entries past its own leaves hold -inf
       rmap[lane] = (isleaf && !inserted) ? (unsigned char)(r + 1) : (unsigned char)0;
       if (inserted) reinterpret_cast<unsigned char*>(csu)[4 * (hb + l_pi) + l_lc] = (unsigned char)(r + 1);
       lds_sync();
