@@ -460,12 +460,14 @@ def split_config(spec, weights, x_dev, s_dev, ref32, device_id):
 
 
 def kernel_sources_digest():
-    """SHA-256 over the HIP sources: a PMC record is only valid for the kernels it was collected on."""
+    """SHA-256 over the KERNEL sources (*.hip and the headers they include): a PMC record is only valid for the kernels it was
+    collected on.  The host-only C++ of the library (fast5.cpp: the HDF5 reader, assemble.cpp: the consensus vote and the finisher)
+    defines no kernel and is left out: hardening the fast5 reader must not withhold a recurrence kernel's HBM traffic."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "chiron_amd", "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h")):
             h.update(name.encode())
             h.update(open(os.path.join(src, name), "rb").read())
     return h.hexdigest()[:16]

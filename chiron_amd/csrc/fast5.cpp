@@ -298,6 +298,7 @@ struct H5 {
   std::string decode_string(const DType& t, const std::vector<uint8_t>& raw) const {
     if (t.kind == 3) {
       const size_t n = std::min<size_t>(t.size, raw.size());
+      if (n == 0) return std::string();            // (memchr on an empty vector's null data() is undefined, however harmless)
       const void* e = memchr(raw.data(), 0, n);
       return std::string(reinterpret_cast<const char*>(raw.data()), e ? (size_t)(reinterpret_cast<const uint8_t*>(e) - raw.data()) : n);
     }

@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "timing_variants.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace chiron {
@@ -1065,13 +1066,22 @@ bool launch_gemm(const GemmParams& p0, hipStream_t stream) {
   const int mblocks = (p.M + GEMM_BM - 1) / GEMM_BM;
   const int total_ids = ((mblocks + 7) / 8) * 8 * nblocks_n;
   const int n_cu = current_device_cus();
-  int g = 2 * n_cu;            // two resident workgroups per CU (69 KB LDS each; 77 KB for the projection layout)
+  // Workgroups per CU of the persistent launches: two are resident at a time (69 KB LDS each; 77 KB for the projection layout).
+  // With tiles by counter a launch may hold MORE workgroups than fit: the extra ones start when a CU frees up -- behind another
+  // batch's recurrence or Winograd workgroup -- and take whatever tiles are left (or leave at once).  CHIRON_GEMM_WGS_PER_CU is
+  // the A/B knob (default 2; only meaningful with dynamic tiles).
+  static const int wgs_per_cu = [] {
+    const char* v = getenv("CHIRON_GEMM_WGS_PER_CU");
+    const int n = v ? atoi(v) : 2;
+    return n >= 1 && n <= 8 ? n : 2;
+  }();
+  int g = wgs_per_cu * n_cu;
   g = (g / 8) * 8;
   if (g > total_ids) g = total_ids;
   const dim3 grid(g), block(256);
   // projections run 128 x 160 tiles on the DMA kernel
   const int total_z = ((mblocks + 7) / 8) * 8 * ((p.N + 159) / 160);
-  const dim3 grid_z(std::min((2 * n_cu / 8) * 8, total_z));
+  const dim3 grid_z(std::min((wgs_per_cu * n_cu / 8) * 8, total_z));
   // dynamic tile numbers (GemmParams::tile_ctr): the DMA kernel uses them when a segment has three chunks or more; a launch
   // takes slots-per-XCD + workgroups-per-XCD numbers from every counter
   const bool zout = p.out_mode == 1;

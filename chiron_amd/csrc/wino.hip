@@ -27,6 +27,8 @@
 #include "kernels.h"
 #include "timing_variants.h"
 
+#include <cstdlib>
+
 namespace chiron {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -532,7 +534,14 @@ bool launch_wino_conv3(const WinoParams& p, hipStream_t stream) {
     }
     __atomic_store_n(&attr_set[dev], (char)1, __ATOMIC_RELEASE);
   }
-  int g = (n_cu / 8) * 8;
+  // one workgroup per CU is resident (121 KB of LDS); with tiles by counter a launch may ask for more: the extra workgroups start
+  // when a CU frees up and take what is left (CHIRON_WINO_WGS_PER_CU: A/B knob, default 1)
+  static const int wgs_per_cu = [] {
+    const char* v = getenv("CHIRON_WINO_WGS_PER_CU");
+    const int n = v ? atoi(v) : 1;
+    return n >= 1 && n <= 4 ? n : 1;
+  }();
+  int g = (wgs_per_cu * n_cu / 8) * 8;
   if (p.f4) {   // F(4,3): U holds six transformed filters, T is a multiple of 4
     if (p.T % 4) return false;
     const int mblocks = (p.B * (p.T / 4) + Q4 - 1) / Q4;

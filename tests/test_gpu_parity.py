@@ -1600,6 +1600,11 @@ def test_sharded_call_equals_single_process(tmp_path):
     assert repl["identical"] and repl["files_compared"] == 18 and repl["consensus_bases"] == rep["consensus_bases"]
     ranks_dir = os.path.join(str(tmp_path / "c"), "chunk_000000", "out_2ranks", "log", "ranks")
     assert sorted(os.listdir(ranks_dir)) == ["barrier.1.0", "barrier.1.1", "barrier.2.0", "barrier.2.1"]
+    # --dtype fp16: every process calibrates its engine at start-up (bias correction for the weights' rounding to halves) on the SAME
+    # fixed synthetic batch, so the sharded run's files are still the single process's, byte for byte
+    rep16 = shard_run.run(str(tmp_path / "d"), n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100, kind="fast5",
+                          launcher="local", dtype="fp16")
+    assert rep16["identical"] and rep16["files_compared"] == 18 and rep16["consensus_bases"] > 0
 
 
 def test_device_consensus_equals_host_vote(tmp_path):

@@ -56,11 +56,11 @@ def write_model_dir(folder):
                    "rnn": {"layer_num": 3, "hidden_num": 100, "cell_type": "LSTM", "layer_type": "normal"}}, f)
 
 
-def call(inp, out, model, ranks, share_gpu, extension="fastq", batch=1100, port=29611, timeout=3600, launcher="torchrun"):
+def call(inp, out, model, ranks, share_gpu, extension="fastq", batch=1100, port=29611, timeout=3600, launcher="torchrun", dtype="fp32"):
     """`chiron call` (python -m chiron_amd.entry) on `ranks` processes; returns wall seconds.  launcher "torchrun": the ranks are
     started by torch.distributed.run (barriers over RCCL / gloo); "local": by `chiron call --gpus N` itself (file barrier, no torch)."""
     cmd = ["-m", "chiron_amd.entry", "call", "-i", inp, "-o", out, "-m", model, "--synthetic-weights", "-b", str(batch),
-           "-l", "400", "-j", "390", "--beam", "0", "-e", extension, "-t", "4"]
+           "-l", "400", "-j", "390", "--beam", "0", "-e", extension, "-t", "4", "--dtype", dtype]
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     if ranks > 1 and launcher == "local":
         cmd += ["--gpus", str(ranks)]
@@ -94,7 +94,7 @@ def compare_trees(a, b, extension):
     return n
 
 
-def run_chunk(workdir, first, n_reads, n_samples, ranks, share_gpu, extension, batch, kind, keep, launcher="torchrun"):
+def run_chunk(workdir, first, n_reads, n_samples, ranks, share_gpu, extension, batch, kind, keep, launcher="torchrun", dtype="fp32"):
     """one chunk: inputs written, 1-rank and R-rank `chiron call`, trees compared, everything deleted again -> record"""
     import hashlib
     import shutil
@@ -105,10 +105,10 @@ def run_chunk(workdir, first, n_reads, n_samples, ranks, share_gpu, extension, b
     write_reads(sig, n_reads, n_samples, first=first, kind=kind)
     write_model_dir(model)
     out1, outn = os.path.join(cdir, "out_1rank"), os.path.join(cdir, "out_%dranks" % ranks)
-    t1 = call(sig, out1, model, 1, False, extension, batch)
+    t1 = call(sig, out1, model, 1, False, extension, batch, dtype=dtype)
     merged1, n1 = shard.gather_results(out1, extension)          # a single process does not gather by itself
     shutil.rmtree(os.path.join(out1, "raw"), ignore_errors=True)   # the largest folder; never compared
-    tn = call(sig, outn, model, ranks, share_gpu, extension, batch, launcher=launcher)
+    tn = call(sig, outn, model, ranks, share_gpu, extension, batch, launcher=launcher, dtype=dtype)
     mergedn = os.path.join(outn, "merged." + extension)
     if n1 != n_reads:
         raise AssertionError("%d reads in, %d results out" % (n_reads, n1))
@@ -124,12 +124,13 @@ def run_chunk(workdir, first, n_reads, n_samples, ranks, share_gpu, extension, b
     return rec
 
 
-def run(workdir, n_reads, n_samples, ranks, share_gpu, extension="fastq", batch=1100, chunk=0, kind="signal", keep=False, launcher="torchrun"):
+def run(workdir, n_reads, n_samples, ranks, share_gpu, extension="fastq", batch=1100, chunk=0, kind="signal", keep=False, launcher="torchrun",
+        dtype="fp32"):
     os.makedirs(workdir, exist_ok=True)
     chunk = chunk if chunk > 0 else n_reads
     state_path = os.path.join(workdir, "state.json")
     key = {"reads": n_reads, "samples_per_read": n_samples, "ranks": ranks, "extension": extension, "batch": batch, "chunk": chunk, "input": kind,
-           "launcher": launcher}
+           "launcher": launcher, "dtype": dtype}
     state = {"key": key, "chunks": {}}
     if os.path.exists(state_path):
         old = json.load(open(state_path))
@@ -138,7 +139,7 @@ def run(workdir, n_reads, n_samples, ranks, share_gpu, extension="fastq", batch=
     for first in range(0, n_reads, chunk):
         if str(first) in state["chunks"]:
             continue
-        state["chunks"][str(first)] = run_chunk(workdir, first, min(chunk, n_reads - first), n_samples, ranks, share_gpu, extension, batch, kind, keep, launcher)
+        state["chunks"][str(first)] = run_chunk(workdir, first, min(chunk, n_reads - first), n_samples, ranks, share_gpu, extension, batch, kind, keep, launcher, dtype)
         tmp = state_path + ".tmp"
         with open(tmp, "w") as f:
             json.dump(state, f, indent=1, sort_keys=True)
@@ -163,12 +164,13 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="reads per chunk (0: all at once); the disk holds one chunk at a time")
     ap.add_argument("--input", default="signal", choices=["signal", "fast5"], help="input files: .signal text or fast5 (direct path)")
     ap.add_argument("--keep", action="store_true", help="keep the chunk folders (inputs and both output trees)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp32-split"])
     ap.add_argument("--launcher", default="torchrun", choices=["torchrun", "local"],
                     help="who starts the ranks: torch.distributed.run, or `chiron call --gpus N` itself (file barrier, no torch)")
     a = ap.parse_args()
     import tempfile
     wd = a.workdir or tempfile.mkdtemp(prefix="chiron_shard_")
-    print(json.dumps(run(wd, a.reads, a.samples, a.ranks, a.share_gpu, a.extension, a.batch, a.chunk, a.input, a.keep, a.launcher)))
+    print(json.dumps(run(wd, a.reads, a.samples, a.ranks, a.share_gpu, a.extension, a.batch, a.chunk, a.input, a.keep, a.launcher, a.dtype)))
 
 
 if __name__ == "__main__":
