@@ -209,3 +209,33 @@ def test_every_environment_switch_of_the_product_is_documented():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     missing = sorted(e for e in found if e not in doc)
     assert not missing, "environment switches not in INTEGRATION.md: %s" % missing
+
+
+def test_the_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: only tests/, tools/ measurement scripts, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+    may import or load anything under it.  The package holds no import of it, no path into it, and bench.py's only use sits inside
+    cpu_baseline()."""
+    import ast
+    pkg = os.path.join(ROOT, "chiron_amd")
+    for dirpath, _, names in os.walk(pkg):
+        for n in names:
+            if n.endswith(".py"):
+                tree = ast.parse(open(os.path.join(dirpath, n)).read())
+                for node in ast.walk(tree):
+                    mods = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""] if isinstance(node, ast.ImportFrom) else []
+                    assert not any(m == "oracle" or m.startswith("oracle.") for m in mods), (n, mods)
+            if n.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, n)).read()
+                assert "libchiron_oracle" not in text and "oracle/_build" not in text, n
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    users = set()
+    for fn in ast.walk(tree):
+        if isinstance(fn, ast.FunctionDef):
+            for node in ast.walk(fn):
+                if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                    users.add(fn.name)
+                if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                    users.add(fn.name)
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any((getattr(n, "module", "") or "").startswith("oracle") or any(a.name.startswith("oracle") for a in n.names) for n in top)
+    assert users == {"cpu_baseline"}, users
