@@ -193,6 +193,7 @@ struct LstmPlan {
   void* whfused = nullptr;  // f16: W_hh in the 16x16x32 order of lstm16f_kernel
   void* wxwide = nullptr;   // f16: input weights in that order (lstm16f_kernel: projection fused into the recurrence)
   int wx_ksteps = 0;        //      its k-steps of 16 (16: K = 256, 13: K = 200)
+  void* wsplit = nullptr;   // fp32-split: W_hh as hi + lo half pairs in the order of wwide (lstm32s_kernel)
   float* wwide32 = nullptr; // fp32: recurrent weights in the 16x16x4 B-operand order of lstm32w_kernel
   float* wlight = nullptr;  // K-split fragment of units 96..99 for the paired recurrence (fp32, H = 100)
 };
@@ -703,6 +704,30 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       }
     } else if ((st = dev_upload(e, &lp.wfrag, wf))) {
       return st;
+    }
+    if (e->split && H == 100 && getenv("CHIRON_SPLIT_REC32") == nullptr) {
+      // lstm32s_kernel: [hi | lo][dir][wave 8][slot 4][k-step 7][lane][4 halves]; lane = kq*16 + 4u + gate, tile = 3 wave + slot (the order
+      // of lstm16w_kernel's fragments), every weight as an exact hi + lo half pair
+      const size_t half = (size_t)2 * 8 * 4 * 7 * 64 * 4;
+      std::vector<_Float16> ws(2 * half, (_Float16)0.f);
+      for (int dir = 0; dir < 2; ++dir)
+        for (int wv = 0; wv < 8; ++wv)
+          for (int slot = 0; slot < (wv == 7 ? 4 : 3); ++slot)
+            for (int ks = 0; ks < 7; ++ks)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int q = 0; q < 4; ++q) {
+                  const int k = 16 * ks + 4 * (lane >> 4) + q, g = lane & 3, unit = 4 * (3 * wv + slot) + ((lane >> 2) & 3);
+                  if (k < H && unit < H) {
+                    const float wv32 = kern[dir][(size_t)(lp.in_w + k) * 4 * H + g * H + unit];
+                    const _Float16 hi = (_Float16)wv32;
+                    const size_t at = (((((size_t)dir * 8 + wv) * 4 + slot) * 7 + ks) * 64 + lane) * 4 + q;
+                    ws[at] = hi;
+                    ws[half + at] = (_Float16)(wv32 - (float)hi);
+                  }
+                }
+      _Float16* dws = nullptr;
+      if ((st = dev_upload(e, &dws, ws))) return st;
+      lp.wsplit = dws;
     }
     if (!e->f16) {
       // light-wave fragment of lstm_pair_kernel: [dir][m = 4q + a][lane = kg*16 + gate*4 + j] = W_hh[16q + 4kg + a][gate*H + 96 + j]
@@ -1314,6 +1339,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.wlight = lp.wlight;
     r.wwide = lp.wwide;
     r.wwide32 = lp.wwide32;
+    r.wsplit = lp.wsplit;
     r.form32 = e->lstm_form;
     r.narrow16 = e->lstm16_narrow ? 1 : 0;
     r.xsrc = nullptr;
@@ -1336,6 +1362,12 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     }
     r.seq_len = s->seq;
     r.out = e->split ? s->lasth_f32 : outbuf;
+    // fp32-split with its own recurrence (lstm32s_kernel): a layer that feeds another projection writes the hi / lo format that
+    // projection reads straight into the layer's lasth buffer -- no fp32 copy, no conversion pass; the last layer writes fp32 for the FC head
+    const bool direct_split = e->split && lp.wsplit != nullptr && l + 1 < e->lstm.size();
+    r.out_split = direct_split ? (void*)outbuf : nullptr;
+    r.split_ld = e->lasth_ld;
+    r.split_bw0 = e->desc.rnn_kind == CHIRON_RNN_MULTI ? roundup(H, 32) : H;
     r.T = T;
     r.B = B;
     r.BP = BP;
@@ -1365,7 +1397,9 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
         calib_measure(e, lp.proj[lp.nproj == 1 ? 0 : dir].shift, 0, outbuf, (long)T * BP, e->lasth_ld, dir * H, H, BP, B, (int)l, dir, 1, s->stream);
     prev = outbuf;
     if (e->split) {
-      if (l + 1 < e->lstm.size()) {
+      if (direct_split) {
+        // nothing to convert
+      } else if (l + 1 < e->lstm.size()) {
         Prof pr(e, s, PN_REC, 0.0, (4.0 + 4.0) * T * BP * 2.0 * H);
         const bool multi = e->desc.rnn_kind == CHIRON_RNN_MULTI;
         launch_split_convert(s->lasth_f32, outbuf, (long)T * BP, 2 * H, e->lasth_ld, multi ? H : 0, multi ? roundup(H, 32) : 0, s->stream);

@@ -143,6 +143,11 @@ struct LstmParams {
                          //   entry m = 4q + a, lane = kg*16 + gate*4 + j  ->  W_hh[k = 16q + 4kg + a][gate*H + 96 + j]
   const float* wwide32;  // fp32 wide form (lstm32w_kernel): [ndir][8 waves][4 tile slots][25 k-steps][64 lanes], lane = kq*16 + 4u + gate ->
                          //   W_hh[k = 4 ks + kq][gate*H + 4 tile + u], tile = 3 wave + slot (zero for the slots a wave does not use)
+  const void* wsplit;    // dtype fp32-split (lstm32s_kernel): W_hh as hi + lo half pairs, [hi | lo] x the order of `wwide`; nullptr: the fp32 kernels
+  void* out_split;       // lstm32s_kernel: when set, the output goes HERE in the split hi / lo format the next layer's projection reads
+                         //   ([T * BP rows][split_ld], per 32-element block 32 hi halves then 32 lo halves) instead of fp32 to `out`
+  int split_ld;          //   elements per row; split_bw0: first element of the backward direction's H columns (H: the directions are
+  int split_bw0;         //   contiguous; roundup(H, 32): MultiRNN, each direction a K-segment of its own)
   int form32;            // fp32: 0 = the 4-row kernels (lstm_kernel), 1 = lstm32w_kernel, 2 = lstm32w2_kernel (CHIRON_LSTM_WIDE)
   const void* wwide;     // f16 wide form: [ndir][8 waves][4 tile slots][7 k-steps][64 lanes][4 halves], lane = kq*16 + 4u + gate ->
                          //   W_hh[k = 16 ks + 4 kq + e][gate*H + 4 tile + u], tile = 3 wave + slot (zero past K or the wave's tiles)

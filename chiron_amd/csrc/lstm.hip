@@ -701,6 +701,165 @@ __global__ __launch_bounds__(64 * W16_NW, 2) void lstm16w_kernel(const LstmParam
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// dtype fp32-split: the recurrence on the f16 matrix pipe with fp32 VALUES.  Same workgroup shape and operand layouts as
+// lstm16w_kernel (sixteen batch rows x one direction, eight waves, wave w owns the column tiles 3w .. 3w+2 (wave 7: four) of 4 units x
+// 4 gates, v_mfma_f32_16x16x16_f16), but h and W_hh are carried as exact hi + lo half pairs (x = hi + lo to 2^-22, the format the
+// split engine's GEMMs already use) and a tile's product is hi*hi + hi*lo + lo*hi with fp32 accumulation: 21 MFMAs of 16 cycles per
+// tile and step instead of the 25 x 32 cycles of v_mfma_f32_16x16x4_f32 -- the recurrence was 4.4 of the split engine's 8.1 ms per batch
+// while it ran the fp32 kernel (plus a conversion pass per layer).  z (fp32, the projection's layout), gates, cell state and the output
+// (fp32 lasth, what the fp32 kernels write) are unchanged, so the engine swaps the kernel and nothing else.  A row's bits do not depend
+// on the batch it travels in (every output element of a 16 x 16 tile depends on its own row and column only).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * W16_NW, 1) void lstm32s_kernel(const LstmParams p) {
+  __shared__ __attribute__((aligned(16))) _Float16 hhi[2 * HW16];
+  __shared__ __attribute__((aligned(16))) _Float16 hlo[2 * HW16];
+  __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * W16_XF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x % p.ndir;
+  const int g16 = blockIdx.x / p.ndir;
+  const int nt = wave == W16_NW - 1 ? 4 : 3;
+  const int tile0 = 3 * wave;
+
+  // W_hh fragments: [hi | lo][dir][wave][slot][k-step][lane] f16x4, the order of LstmParams::wwide
+  f16x4 wh[W16_NT][W16_KS], wl[W16_NT][W16_KS];
+  {
+    const long half = (long)p.ndir * W16_NW * W16_NT * W16_KS * 64;
+    const f16x4* wf = reinterpret_cast<const f16x4*>(p.wsplit) + ((long)dir * W16_NW + wave) * W16_NT * W16_KS * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+#pragma unroll
+      for (int ks = 0; ks < W16_KS; ++ks) {
+        wh[n][ks] = wf[(n * W16_KS + ks) * 64];
+        wl[n][ks] = wf[half + (n * W16_KS + ks) * 64];
+      }
+  }
+  for (int i = tid; i < 2 * HW16; i += 64 * W16_NW) hhi[i] = (_Float16)0.f, hlo[i] = (_Float16)0.f;
+
+  const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;   // before the transpose: column 4u + gp, rows 4q .. 4q+3
+  const int row = 4 * q + gp;                                      // after it: this lane's cell is (row, unit 4 tile + u)
+  const int brow = g16 * 16 + row;
+  const int lenr = min(p.seq_len[brow], p.T);
+  int maxlen = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) maxlen = max(maxlen, min(p.seq_len[g16 * 16 + r], p.T));
+  __syncthreads();
+
+  const unsigned outw = p.ndir * p.H;
+  const unsigned zcols = 4 * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;        // floats between consecutive steps
+  // byte offset of this lane's 4 floats (rows 4q..4q+3 of column gate*H + unit) for tile slot 0; + 64 bytes per tile
+  const unsigned zlane_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 4 * tile0 + u) * 4) * 4;
+  const unsigned ostep = p.BP * outw;
+  const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;  // + 4 per tile
+  const int hw = tile0 * 64 + row * 4 + u;                          // + 64 per tile
+  float* outf = p.out;
+  // split-format destination (layers that feed another projection): element column of this lane's unit in tile slot n, and the
+  // half index of its hi value inside a row (the lo value sits 32 halves further)
+  _Float16* const outs = reinterpret_cast<_Float16*>(p.out_split);
+  const unsigned srow = 2u * p.split_ld;                             // halves per row
+  // the copy-out thread's (tile = tid / 16, row = tid % 16): its row's length and the half index of the tile's four hi values in a row
+  const int olens = (outs && tid < 25 * 16) ? min(p.seq_len[g16 * 16 + (tid & 15)], p.T) : 0;
+  const unsigned ocol0 = (dir == 0 ? 0u : (unsigned)p.split_bw0) + 4u * (tid >> 4);
+  const unsigned ocol = (ocol0 >> 5) * 64 + (ocol0 & 31);
+
+  float* const xw = xf + wave * W16_NT * W16_XF + 4 * lane + 4 * q;
+  const float* const xr = xf + wave * W16_NT * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+
+  // Split-format output leaves from the completed h tiles: thread (tile, row) copies the 4 units of its tile -- 8 bytes of hi halves
+  // and 8 bytes of lo halves, exactly the pair the next step multiplies -- instead of two 2-byte stores per cell (1600 x 2 per step:
+  // 0.83 ms per launch against 0.61 with fp32 output).  A row past its length holds its carried state there and is written as zeros.
+  // Step sp's h is the INPUT tile of step sp + 1 (stable for that whole step), and the copy is issued there BEHIND the wait for z:
+  // vmcnt counts stores too, and a store issued in front of that wait makes every step wait for its own write acknowledgements.
+  auto copy_out = [&](int sp, int buf) {
+    if (outs && sp >= 0 && tid < 25 * 16) {
+      const int ot = tid >> 4, orow = tid & 15;
+      const bool oact = sp < olens;
+      const unsigned oto = (dir == 0 || !oact) ? sp : olens - 1 - sp;
+      f16x4 vh = *reinterpret_cast<const f16x4*>(hhi + buf * HW16 + ot * 64 + orow * 4);
+      f16x4 vl = *reinterpret_cast<const f16x4*>(hlo + buf * HW16 + ot * 64 + orow * 4);
+      if (!oact) vh = vl = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      _Float16* o = outs + (size_t)(oto * p.BP + g16 * 16 + orow) * srow + ocol;
+      *reinterpret_cast<f16x4*>(o) = vh;
+      *reinterpret_cast<f16x4*>(o + 32) = vl;
+    }
+  };
+  float c[W16_NT] = {0.f, 0.f, 0.f, 0.f}, hprev[W16_NT] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (int s = 0; s < maxlen; ++s) {
+    const float* zs = p.z + (size_t)s * zstep;   // wave-uniform
+    f32x4 zv[W16_NT];
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zv[0]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(zv[1]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=v"(zv[2]) : "v"(zlane_b), "s"(zs) : "memory");
+    if (nt == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192" : "=v"(zv[3]) : "v"(zlane_b), "s"(zs) : "memory");
+    else zv[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f16x4* hbh = reinterpret_cast<const f16x4*>(hhi + cur * HW16) + lane;
+    const f16x4* hbl = reinterpret_cast<const f16x4*>(hlo + cur * HW16) + lane;
+    f16x4 hvh[W16_KS], hvl[W16_KS];
+#pragma unroll
+    for (int ks = 0; ks < W16_KS; ++ks) hvh[ks] = hbh[ks * 64], hvl[ks] = hbl[ks * 64];
+    f32x4 acc[W16_NT];
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n < nt) {
+        // the two cross terms first (2^-11 of the main term each), then hi * hi: the small addends are not rounded against a large sum
+#pragma unroll
+        for (int ks = 0; ks < W16_KS; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(hvl[ks], wh[n][ks], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < W16_KS; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(hvh[ks], wl[n][ks], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < W16_KS; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(hvh[ks], wh[n][ks], acc[n], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    copy_out(s - 1, cur);
+    const bool act = s < lenr;
+    const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+      if (n < nt) *reinterpret_cast<f32x4*>(xw + n * W16_XF) = acc[n] + zv[n];
+    __builtin_amdgcn_wave_barrier();   // wave-private scratch: LDS operations of a wave execute in order
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      if (n < nt) {
+        const float* xs = xr + n * W16_XF;
+        const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};   // i, j, f, o of (row, unit 4 (tile0 + n) + u)
+        float hnew;
+        const float cn = lstm_cell(gates, c[n], &hnew);
+        c[n] = act ? cn : c[n];
+        hprev[n] = act ? hnew : hprev[n];
+        const _Float16 hi = (_Float16)hprev[n];
+        hhi[(cur ^ 1) * HW16 + hw + 64 * n] = hi;
+        hlo[(cur ^ 1) * HW16 + hw + 64 * n] = (_Float16)(hprev[n] - (float)hi);
+        if (!outs) outf[to * ostep + olane + 4 * n] = act ? hnew : 0.f;
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  copy_out(maxlen - 1, cur);   // the last step's h
+
+  // ---- frames past the longest row of the workgroup read back as zeros (dynamic_rnn semantics)
+  for (int s = maxlen; s < p.T; ++s)
+    for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
+      const int r = i / p.H;
+      const int uu = i - r * p.H;
+      if (outs) {
+        const unsigned col = (dir == 0 ? 0u : (unsigned)p.split_bw0) + uu;
+        _Float16* o = outs + ((size_t)s * p.BP + g16 * 16 + r) * srow + (col >> 5) * 64 + (col & 31);
+        o[0] = (_Float16)0.f;
+        o[32] = (_Float16)0.f;
+      } else {
+        outf[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = 0.f;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // f16, wide AND fused with the x-projection: the same 16-row workgroups as lstm16w_kernel, but z is never materialised.
 // At B = 4096 the projection GEMM writes 2.6 GB of z per layer and the recurrence reads it back -- 5.2 GB of HBM traffic and
 // a 1.25 ms launch per layer for a product the recurrence's idle matrix pipe can do itself: per step the workgroup gathers
@@ -1391,6 +1550,10 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
     if (wide > 0) hipLaunchKernelGGL(lstm16w_kernel, dim3(wide * p.ndir), dim3(64 * W16_NW), 0, stream, p);
     p.group0 = 4 * wide;
     if (groups > p.group0) hipLaunchKernelGGL(lstm16_kernel, dim3((groups - p.group0) * p.ndir), dim3(64 * LSTM_NW), 0, stream, p);
+    return;
+  }
+  if (p.wsplit) {   // dtype fp32-split: the recurrence on the f16 pipe (hi + lo pairs), sixteen-row workgroups for every row of the padded batch
+    hipLaunchKernelGGL(lstm32s_kernel, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
     return;
   }
   if (p.wwide32 && p.form32 > 0 && !p.paired) {   // sixteen-row workgroups for every row of the padded batch

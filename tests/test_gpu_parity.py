@@ -1003,6 +1003,45 @@ def test_f32_split_dtype_meets_the_fp32_parity_bound(dna):
         assert rows[b] == orows[b]
 
 
+@pytest.mark.parametrize("topology", ["dna", "rna"])
+def test_split_recurrence_on_the_f16_pipe_against_the_fp32_recurrence(dna, rna, monkeypatch, topology):
+    """dtype fp32-split, round 4: the recurrence itself runs on the f16 matrix pipe (lstm32s_kernel: h and W_hh as exact hi + lo half
+    pairs, hi*hi + hi*lo + lo*hi with fp32 accumulation; layers that feed another projection write the split format directly, from
+    the completed h tiles).  CHIRON_SPLIT_REC32=1 keeps the fp32 recurrence kernel + conversion pass of rounds 1 .. 3.  Both must meet
+    the 1e-4 bound against the float64 oracle and agree with each other far inside it, on ragged batches (lengths 0, 1, full), for the
+    stacked BiLSTM and for the MultiRNN graph (backward half on its own 32-element block), deterministically and independently of a
+    row's position in the batch; frames at or past a row's length must give the same logits in both (the zeros the kernels write)."""
+    from oracle import nn_oracle
+    spec, w = dna if topology == "dna" else rna
+    L, jump = (400, 390) if topology == "dna" else (500, 490)
+    x, ln = _windows(jump * 44 + 77, L, jump, seed=63)
+    B = x.shape[0]
+    rng = np.random.RandomState(5)
+    ln = ln.copy()
+    ln[:6] = [0, 1, L - 1, L // 2, 37, L]
+    ln[6:24] = rng.randint(1, L + 1, size=18)
+    for b in range(B):
+        x[b, ln[b]:] = 0
+    outs = {}
+    for name, env in (("f16-pipe", None), ("fp32-kernel", "1")):
+        if env is None:
+            monkeypatch.delenv("CHIRON_SPLIT_REC32", raising=False)
+        else:
+            monkeypatch.setenv("CHIRON_SPLIT_REC32", env)
+        with ca.Engine(spec, w, max_batch=B + 5, segment_len=L, dtype="fp32-split") as es:
+            sl = ca.seq_len_for_engine(ln, es.ratio)
+            r = es.infer(x, sl, want_logits=True)
+            assert np.array_equal(es.infer(x, sl, want_logits=True).logits, r.logits)
+            one = es.infer(x[9:10], sl[9:10], want_logits=True)
+            assert np.array_equal(one.logits[0], r.logits[9])
+            outs[name] = r.logits
+    monkeypatch.delenv("CHIRON_SPLIT_REC32", raising=False)
+    ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
+    for name, lg in outs.items():
+        assert np.abs(lg.astype(np.float64) - ref).max() < TOL, name
+    assert np.abs(outs["f16-pipe"] - outs["fp32-kernel"]).max() < 5e-5
+
+
 def test_f16_path_tolerance_vs_f32(dna, rna):
     """BASELINE configs[4]: fp16 conv + LSTM on the f16 MFMA instructions, fp32 accumulation / gates / CTC.
     Tolerance check against the fp32 engine on identical inputs (the fp32 engine is itself within 1e-4 of the
