@@ -790,6 +790,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
   // cycles per VALU instruction with two waves per SIMD), so the per-tile bookkeeping is kept off the VALU:
   // the accumulators are never zeroed and the shift is never added -- the first MFMA of a tile takes its C
   // operand from a register vector holding the shift (read from LDS), D = acc.
+#if CHIRON_SENS & 1024
+  // timing experiment: where a wave's cycles go (s_memtime): the barrier in front of each chunk of a tile's first segment, the
+  // epilogue, whole tiles; wave 0 of four workgroups prints (tools/gemm_clk.py condenses)
+  unsigned long long clk_bar[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clk_epi = 0, clk_tiles = 0;
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime();
+#endif
   while (c_id < total_ids) {
     int m0, n0;
     tile_of(c_id, m0, n0);
@@ -804,7 +810,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
       // one K-chunk: barrier, start the DMA of the chunk after it, run this one on the matrix pipe
       auto chunk = [&](auto cc) {
         constexpr int C = decltype(cc)::value;
+#if CHIRON_SENS & 1024
+        const unsigned long long clk_b0 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();  // chunk in `buf` has landed (vmcnt drained before the barrier); buf^1 is free
+#if CHIRON_SENS & 1024
+        if (FS) clk_bar[C] += __builtin_amdgcn_s_memtime() - clk_b0;
+#endif
         if (FS && dyn) {   // the next tile's number: requested, published one barrier later (it has returned by then), read after the next
           if (C == 0) issue_grab();
           if (C == 1 && tid == 0) sh_next = decode_grab();
@@ -845,8 +857,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
           // (Round 3: BEFORE the shift vectors below are built, so that these take the registers the epilogue has just
           // released -- built first, the projection's 5 x 16 of them sat next to its 80 accumulators: 226 .. 237 registers,
           // and no such wave fits next to two recurrence waves on a SIMD; now it does.)
+#if CHIRON_SENS & 1024
+          const unsigned long long clk_e0 = __builtin_amdgcn_s_memtime();
+#endif
           if (have_prev) epilogue(pm0, pn0);
           asm volatile("" ::: "memory");
+#if CHIRON_SENS & 1024
+          clk_epi += __builtin_amdgcn_s_memtime() - clk_e0;
+#endif
           // C operand of the tile's first MFMAs: this lane's 16 shift values per 32-column block, written INTO the accumulators
           // (a separate vector is not coalesced with them by the register allocator: 80 more live registers in the projection)
 #pragma unroll
@@ -984,8 +1002,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
     pm0 = m0;
     pn0 = n0;
     c_id = n_id;
+#if CHIRON_SENS & 1024
+    ++clk_tiles;
+#endif
   }
   if (have_prev) epilogue(pm0, pn0);
+#if CHIRON_SENS & 1024
+  if (tid == 0 && blockIdx.x < 4 && clk_tiles > 0)
+    printf("gemm_clk zout %d K %d block %d: tiles %llu, cycles per tile: total %llu, epilogue %llu, barriers %llu %llu %llu %llu %llu %llu %llu %llu\n",
+           (int)ZOUT, p.K, (int)blockIdx.x, clk_tiles, (__builtin_amdgcn_s_memtime() - clk_t0) / clk_tiles, clk_epi / clk_tiles, clk_bar[0] / clk_tiles,
+           clk_bar[1] / clk_tiles, clk_bar[2] / clk_tiles, clk_bar[3] / clk_tiles, clk_bar[4] / clk_tiles, clk_bar[5] / clk_tiles, clk_bar[6] / clk_tiles,
+           clk_bar[7] / clk_tiles);
+#endif
 }
 
 // The unrolled DMA loop is instantiated for the K-segment widths of the shipped topologies (256 channels;

@@ -290,7 +290,7 @@ def test_read_collector_orders_pieces_by_window_index():
         val = np.asarray([(base + r) % 4 for r in range(batch_rows)], dtype=np.int64)
         res = DecodeResult(SparseTensor(ind, val, np.asarray([batch_rows, 1])), np.zeros((batch_rows, 1), np.float32),
                            np.arange(batch_rows, dtype=np.float32).reshape(-1, 1) + base, None)
-        return ce.Batch(None, None, fn, idx, batch_rows), res
+        return ce.Batch.from_tags(None, None, fn, idx, batch_rows), res
     b2, r2 = mk(4, 5, 5)
     b0, r0 = mk(1, 0, 0)
     b1, r1 = mk(4, 1, 1)
