@@ -357,6 +357,7 @@ def main():
     eng.close()
     if ref32 is not None:
         out["extra"]["config5_f16"] = f16_config(spec, weights, x_dev, s_dev, ref32, local_rank)
+        out["extra"]["config5_f16_w2"] = f16_config(spec, weights, x_dev, s_dev, ref32, local_rank, dtype="fp16-w2")
         out["extra"]["f32_split_dtype"] = split_config(spec, weights, x_dev, s_dev, ref32, local_rank)
     if world > 1:
         dist.barrier()
@@ -393,17 +394,18 @@ class StubEngine(object):
         pass
 
 
-def f16_config(spec, weights, x_dev, s_dev, ref32, device_id):
+def f16_config(spec, weights, x_dev, s_dev, ref32, device_id, dtype="fp16"):
     """BASELINE.json configs[4] (a parity-test case, reported next to the headline, never as `value`): fp16 conv +
     LSTM on the f16 MFMA instructions with fp32 accumulation / gates / CTC, batch 4096, same synthetic workload;
-    plus the tolerance check of its logits against the fp32 engine on the first 1100 windows."""
+    plus the tolerance check of its logits against the fp32 engine on the first 1100 windows.  dtype "fp16-w2": the same
+    activations against exact (hi + lo) weights -- the mode for trained checkpoints (include/chiron_amd.h CHIRON_F16_W2)."""
     import torch
     import chiron_amd as ca
     B16, steps = 4096, 6
     reps = -(-B16 // BATCH)
     x = torch.cat([x_dev[i % len(x_dev)] for i in range(reps)])[:B16].contiguous()
     sl = torch.cat([s_dev[i % len(s_dev)] for i in range(reps)])[:B16].contiguous()
-    with ca.Engine(spec, weights, max_batch=B16, segment_len=SEG_LEN, device_id=device_id, n_slots=2, dtype="fp16") as e16:
+    with ca.Engine(spec, weights, max_batch=B16, segment_len=SEG_LEN, device_id=device_id, n_slots=2, dtype=dtype) as e16:
         r16 = e16.infer(x_dev[0], s_dev[0], want_logits=True)
         T = r16.logits.shape[1]
         mask = np.arange(T)[None, :] < s_dev[0].cpu().numpy()[:, None]
@@ -422,7 +424,8 @@ def f16_config(spec, weights, x_dev, s_dev, ref32, device_id):
             e16.collect(i)
         e16.sync()
         dt = time.perf_counter() - t0
-    return {"workload": "DNA_default seg_len=400 jump=390 batch=4096 greedy, fp16 conv+LSTM / fp32 accumulate, gates, CTC",
+    return {"workload": "DNA_default seg_len=400 jump=390 batch=4096 greedy, fp16 conv+LSTM / fp32 accumulate, gates, CTC"
+                        + (" -- weights as hi + lo half pairs (dtype fp16-w2)" if dtype == "fp16-w2" else ""),
             "kbases_per_s": round(steps * B16 * BASES_PER_WINDOW / 1000.0 / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3),
             "logits_vs_f32": {"max_abs": round(float(d.max()), 5), "mean_abs": round(float(d.mean()), 6), "windows": BATCH}}
 

@@ -19,7 +19,7 @@ ABI_VERSION = 5      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding w
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
-F32, F16, F32_SPLIT = 0, 1, 2
+F32, F16, F32_SPLIT, F16_W2 = 0, 1, 2, 3
 X_ON_DEVICE, WANT_PROB, WANT_LOGITS, NO_DECODE_COPY = 1, 2, 4, 8
 KERNAL_GLUE, KERNAL_STICK, KERNAL_SIMPLE = 1, 2, 3
 

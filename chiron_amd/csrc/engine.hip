@@ -275,6 +275,8 @@ struct chiron_engine {
   bool lstm_paired = false;  // fp32 recurrence: 14-wave workgroups for the part of a batch that fits one resident round
   bool bn_batch = false;  // desc.bn_mode == CHIRON_BN_BATCH
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
+  bool w2 = false;     // opts.dtype == CHIRON_F16_W2: an f16 engine (f16 is set too) whose weights are exact hi + lo half pairs -- every GEMM
+                       // runs its K-segments twice ([x, x] . [W_hi; W_lo], tiled DMA GEMMs only), z stays fp32, the recurrence is lstm16w2_kernel
   bool split = false;  // opts.dtype == CHIRON_F32_SPLIT: fp32 values as hi/lo half pairs on the f16 matrix cores (GEMMs only)
   int lasth_ld = 0;    // elements per lasth row (2H; split: rounded up to whole 32-element blocks)
   int kq = GEMM_BK;    // K padding quantum in elements: one LDS chunk = 128 bytes per row (32 floats / 64 halves)
@@ -341,6 +343,19 @@ static chiron_status upload_gemm(chiron_engine* e, ConvGemmPlan* g, const std::v
       h[blk * 64 + el] = hi;
       h[blk * 64 + 32 + el] = (_Float16)(Wt[i] - (float)hi);
     }
+    _Float16* d = nullptr;
+    if ((st = dev_upload(e, &d, h))) return st;
+    g->Wt = reinterpret_cast<float*>(d);
+  } else if (e->w2) {
+    // every row [K hi halves | K lo halves]: launch() runs the K-segments of a GEMM twice, the second time against the lo columns
+    std::vector<_Float16> h(2 * Wt.size());
+    for (int n = 0; n < Npad; ++n)
+      for (int k = 0; k < K; ++k) {
+        const float v = Wt[(size_t)n * K + k];
+        const _Float16 hi = (_Float16)v;
+        h[(size_t)n * 2 * K + k] = hi;
+        h[(size_t)n * 2 * K + K + k] = (_Float16)(v - (float)hi);
+      }
     _Float16* d = nullptr;
     if ((st = dev_upload(e, &d, h))) return st;
     g->Wt = reinterpret_cast<float*>(d);
@@ -705,7 +720,8 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
     } else if ((st = dev_upload(e, &lp.wfrag, wf))) {
       return st;
     }
-    if (e->split && H == 100 && getenv("CHIRON_SPLIT_REC32") == nullptr) {
+    if (e->w2 && H != 100) return fail(CHIRON_ERR_INVALID, "dtype f16-w2: the recurrence kernel is built for hidden=100");
+    if ((e->w2 || (e->split && getenv("CHIRON_SPLIT_REC32") == nullptr)) && H == 100) {
       // lstm32s_kernel: [hi | lo][dir][wave 8][slot 4][k-step 7][lane][4 halves]; lane = kq*16 + 4u + gate, tile = 3 wave + slot (the order
       // of lstm16w_kernel's fragments), every weight as an exact hi + lo half pair
       const size_t half = (size_t)2 * 8 * 4 * 7 * 64 * 4;
@@ -787,10 +803,10 @@ static chiron_status plan_sizes(const chiron_model_desc* d, const chiron_engine_
   if (st) return st;
   if (!o) return fail(CHIRON_ERR_INVALID, "null opts");
   if (o->max_batch < 1 || o->segment_len < 1) return fail(CHIRON_ERR_INVALID, "max_batch/segment_len must be positive");
-  if (o->dtype != CHIRON_F32 && o->dtype != CHIRON_F16 && o->dtype != CHIRON_F32_SPLIT)
-    return fail(CHIRON_ERR_INVALID, "dtype %d unknown (0 = f32, 1 = f16, 2 = f32 as hi/lo half pairs)", o->dtype);
+  if (o->dtype != CHIRON_F32 && o->dtype != CHIRON_F16 && o->dtype != CHIRON_F32_SPLIT && o->dtype != CHIRON_F16_W2)
+    return fail(CHIRON_ERR_INVALID, "dtype %d unknown (0 = f32, 1 = f16, 2 = f32 as hi/lo half pairs, 3 = f16 activations against hi/lo weights)", o->dtype);
   if (o->max_beam < 0) return fail(CHIRON_ERR_INVALID, "max_beam %d", o->max_beam);
-  const bool f16 = o->dtype == CHIRON_F16, split = o->dtype == CHIRON_F32_SPLIT, bn_batch = d->bn_mode == CHIRON_BN_BATCH;
+  const bool f16 = o->dtype == CHIRON_F16 || o->dtype == CHIRON_F16_W2, split = o->dtype == CHIRON_F32_SPLIT, bn_batch = d->bn_mode == CHIRON_BN_BATCH;
   const uint64_t B = (uint64_t)o->max_batch, BP = (uint64_t)roundup(o->max_batch, 16), L = (uint64_t)o->segment_len, H = d->hidden, K = d->classes;
   int t = o->segment_len, left = 0;
   uint64_t tmax = 0, cmax = 0;
@@ -916,7 +932,8 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->K = desc->classes;
   e->maxB = opts->max_batch;
   e->BP = roundup(opts->max_batch, 16);
-  e->f16 = opts->dtype == CHIRON_F16;
+  e->w2 = opts->dtype == CHIRON_F16_W2;
+  e->f16 = opts->dtype == CHIRON_F16 || e->w2;
   e->split = opts->dtype == CHIRON_F32_SPLIT;
   e->kq = e->f16 ? 2 * GEMM_BK : GEMM_BK;
   // split: rows hold whole 32-element blocks; MultiRNN reads each direction as its own K-segment, so the backward half
@@ -938,7 +955,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   }
   e->lstm16_narrow = getenv("CHIRON_LSTM16_NARROW") != nullptr;
   e->lstm16_pair = getenv("CHIRON_LSTM16_PAIR") ? atoi(getenv("CHIRON_LSTM16_PAIR")) : -1;
-  e->stream16 = getenv("CHIRON_NO_STREAM16") == nullptr;
+  e->stream16 = getenv("CHIRON_NO_STREAM16") == nullptr && opts->dtype != CHIRON_F16_W2;   // (the streaming kernels hold ONE half per weight in registers)
   e->stream32 = getenv("CHIRON_NO_STREAM32") == nullptr;
   e->dyn_tiles = getenv("CHIRON_STATIC_TILES") == nullptr;   // A/B switch: fixed tile shares per workgroup
   {
@@ -947,9 +964,9 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     // take 0.66 ms at B = 512, 1.18 at 1100, 1.9 at 2048; measured per batch 2.04 vs 2.18 / 3.36 vs 4.12 / 5.33 vs 6.84 ms).
     // CHIRON_LSTM16_UNFUSED=1 keeps the projection GEMM + z (A/B switch), CHIRON_LSTM16_FUSED_MIN=<workgroups> moves the threshold.
     const int min_groups = getenv("CHIRON_LSTM16_FUSED_MIN") ? atoi(getenv("CHIRON_LSTM16_FUSED_MIN")) : 64;
-    e->lstm16_fused = e->f16 && !e->lstm16_narrow && desc->hidden == 100 && (e->BP / 16) * 2 >= min_groups && getenv("CHIRON_LSTM16_UNFUSED") == nullptr;
+    e->lstm16_fused = e->f16 && !e->w2 && !e->lstm16_narrow && desc->hidden == 100 && (e->BP / 16) * 2 >= min_groups && getenv("CHIRON_LSTM16_UNFUSED") == nullptr;
   }
-  if (e->f16) e->host_weights.assign(weights, weights + n_floats);
+  if (e->f16 && !e->w2) e->host_weights.assign(weights, weights + n_floats);
   st = build_plans(e, weights);
   const double t_plans = now();
   if (st == CHIRON_OK) {
@@ -1075,6 +1092,12 @@ static bool launch(chiron_engine* e, GemmParams& g, hipStream_t stream) {
     }
     g.K /= 2;
     if (g.out_mode == 0) g.ldo /= 2;
+    if (e->w2) {   // [x, x] . [W_hi; W_lo]: the same A segments again, against the lo columns of the weight rows (upload_gemm)
+      if (2 * g.nseg > GEMM_MAX_SEG) return false;
+      for (int i = 0; i < g.nseg; ++i) g.seg[g.nseg + i] = g.seg[i];
+      g.nseg *= 2;
+      g.K *= 2;
+    }
   }
   return launch_gemm(g, stream);
 }
@@ -1327,7 +1350,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
       g.z_ndir = lp.nproj == 1 ? 2 : 1;
       g.z_dir0 = lp.nproj == 1 ? 0 : pj;
       g.z_seq_len = s->seq;
-      g.z_f16 = e->f16 ? 1 : 0;
+      g.z_f16 = (e->f16 && !e->w2) ? 1 : 0;
       const double ndir = lp.nproj == 1 ? 2.0 : 1.0;
       // layer 0 reads the CNN features (K = 256: its own kernel instantiation), the other layers the recurrent output
       Prof pr(e, s, l == 0 ? PN_PROJ0 : PN_PROJ, 2.0 * B * T * (double)lp.in_w * 4 * H * ndir, 4.0 * B * T * (lp.in_w + ndir * zc));
@@ -1377,6 +1400,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.fixed_roles = e->lstm_fixed_roles ? 1 : 0;
     r.group0 = 0;
     r.f16 = e->f16 ? 1 : 0;
+    r.w2 = e->w2 ? 1 : 0;
     if (e->calib && e->f16) {
       // x rows of the layer's kernels: the means of the layer's input (features: batch-major rows; lasth: time-major)
       for (int pj = 0; pj < lp.nproj; ++pj) {
@@ -1678,7 +1702,7 @@ extern "C" chiron_status chiron_engine_calibrate(chiron_engine* e, const float* 
   if (!x || !seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
   if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
   if (iterations < 0 || iterations > 16) return fail(CHIRON_ERR_INVALID, "iterations %d", iterations);
-  if (!e->f16) return CHIRON_OK;      // fp32 / fp32-split weights are not rounded: nothing to correct
+  if (!e->f16 || e->w2) return CHIRON_OK;      // fp32 / fp32-split / hi + lo weights are not rounded: nothing to correct
   Slot* s = &e->slots[0];
   for (Slot& sl : e->slots)
     if (sl.state.v.load(std::memory_order_acquire) != 0) return fail(CHIRON_ERR_STATE, "chiron_engine_calibrate needs every slot idle");

@@ -168,6 +168,7 @@ struct LstmParams {
   int group0;            // first 4-row group this launch covers (blockIdx 0); launch_lstm splits a batch into a paired part
                          //   and a remainder
   int narrow16;          // f16: 1 = 4-row workgroups only (A/B switch CHIRON_LSTM16_NARROW)
+  int w2;                // f16 engine with hi + lo weights (CHIRON_F16_W2): wsplit holds W_hh, z arrives as fp32, out as halves (lstm16w2_kernel)
   int f16;               // 1: wfrag holds halves in 4x4x4 fragment order, out (lasth) is written as halves; z stays fp32
 };
 void launch_lstm(const LstmParams& p, hipStream_t stream);

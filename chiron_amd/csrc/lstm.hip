@@ -860,6 +860,118 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32s_kernel(const LstmParam
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// dtype f16-w2 (CHIRON_F16_W2): lstm16w_kernel's recurrence -- h as halves, the same workgroup shape, operand layouts, transpose and
+// cell -- against EXACT recurrent weights: W_hh as hi + lo half pairs (lstm32s_kernel's fragments), h*lo then h*hi per tile and step
+// (14 MFMAs of 16 cycles), z read as fp32 (the projection of this dtype does not round it), the output written as halves for the
+// next layer's projection / the FC head.  A row's bits do not depend on the batch it travels in.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * W16_NW, 1) void lstm16w2_kernel(const LstmParams p) {
+  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * HW16];
+  __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * W16_XF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.x % p.ndir;
+  const int g16 = blockIdx.x / p.ndir;
+  const int nt = wave == W16_NW - 1 ? 4 : 3;
+  const int tile0 = 3 * wave;
+
+  f16x4 wh[W16_NT][W16_KS], wl[W16_NT][W16_KS];
+  {
+    const long half = (long)p.ndir * W16_NW * W16_NT * W16_KS * 64;
+    const f16x4* wf = reinterpret_cast<const f16x4*>(p.wsplit) + ((long)dir * W16_NW + wave) * W16_NT * W16_KS * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+#pragma unroll
+      for (int ks = 0; ks < W16_KS; ++ks) {
+        wh[n][ks] = wf[(n * W16_KS + ks) * 64];
+        wl[n][ks] = wf[half + (n * W16_KS + ks) * 64];
+      }
+  }
+  for (int i = tid; i < 2 * HW16; i += 64 * W16_NW) hbuf[i] = (_Float16)0.f;
+
+  const int q = lane >> 4, u = (lane >> 2) & 3, gp = lane & 3;   // before the transpose: column 4u + gp, rows 4q .. 4q+3
+  const int row = 4 * q + gp;                                      // after it: this lane's cell is (row, unit 4 tile + u)
+  const int brow = g16 * 16 + row;
+  const int lenr = min(p.seq_len[brow], p.T);
+  int maxlen = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) maxlen = max(maxlen, min(p.seq_len[g16 * 16 + r], p.T));
+  __syncthreads();
+
+  const unsigned outw = p.ndir * p.H;
+  const unsigned zcols = 4 * p.H;
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;        // floats between consecutive steps
+  const unsigned zlane_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 4 * tile0 + u) * 4) * 4;   // bytes; + 64 per tile
+  const unsigned ostep = p.BP * outw;
+  const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;  // + 4 per tile
+  const int hw = tile0 * 64 + row * 4 + u;                          // + 64 per tile
+  _Float16* outh = reinterpret_cast<_Float16*>(p.out);
+
+  float* const xw = xf + wave * W16_NT * W16_XF + 4 * lane + 4 * q;
+  const float* const xr = xf + wave * W16_NT * W16_XF + 16 * (4 * q + u) + 4 * q + gp;
+
+  float c[W16_NT] = {0.f, 0.f, 0.f, 0.f}, hprev[W16_NT] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (int s = 0; s < maxlen; ++s) {
+    const float* zs = p.z + (size_t)s * zstep;   // wave-uniform
+    f32x4 zv[W16_NT];
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zv[0]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(zv[1]) : "v"(zlane_b), "s"(zs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=v"(zv[2]) : "v"(zlane_b), "s"(zs) : "memory");
+    if (nt == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192" : "=v"(zv[3]) : "v"(zlane_b), "s"(zs) : "memory");
+    else zv[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f16x4* hb = reinterpret_cast<const f16x4*>(hbuf + cur * HW16) + lane;
+    f16x4 hv[W16_KS];
+#pragma unroll
+    for (int ks = 0; ks < W16_KS; ++ks) hv[ks] = hb[ks * 64];
+    f32x4 acc[W16_NT];
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n < nt) {
+        // the small term first: it is not rounded against a large sum
+#pragma unroll
+        for (int ks = 0; ks < W16_KS; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(hv[ks], wl[n][ks], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < W16_KS; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(hv[ks], wh[n][ks], acc[n], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    const bool act = s < lenr;
+    const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n)
+      if (n < nt) *reinterpret_cast<f32x4*>(xw + n * W16_XF) = acc[n] + zv[n];
+    __builtin_amdgcn_wave_barrier();   // wave-private scratch: LDS operations of a wave execute in order
+#pragma unroll
+    for (int n = 0; n < W16_NT; ++n) {
+      if (n < nt) {
+        const float* xs = xr + n * W16_XF;
+        const f32x4 gates = {xs[0], xs[4], xs[8], xs[12]};   // i, j, f, o of (row, unit 4 (tile0 + n) + u)
+        float hnew;
+        const float cn = lstm_cell(gates, c[n], &hnew);
+        c[n] = act ? cn : c[n];
+        hprev[n] = act ? hnew : hprev[n];
+        hbuf[(cur ^ 1) * HW16 + hw + 64 * n] = (_Float16)hprev[n];
+        outh[to * ostep + olane + 4 * n] = (_Float16)(act ? hnew : 0.f);
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+
+  // ---- frames past the longest row of the workgroup read back as zeros (dynamic_rnn semantics)
+  for (int s = maxlen; s < p.T; ++s)
+    for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
+      const int r = i / p.H;
+      const int uu = i - r * p.H;
+      outh[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // f16, wide AND fused with the x-projection: the same 16-row workgroups as lstm16w_kernel, but z is never materialised.
 // At B = 4096 the projection GEMM writes 2.6 GB of z per layer and the recurrence reads it back -- 5.2 GB of HBM traffic and
 // a 1.25 ms launch per layer for a product the recurrence's idle matrix pipe can do itself: per step the workgroup gathers
@@ -1541,6 +1653,10 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
       else
         hipLaunchKernelGGL((lstm16f_kernel<7, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 3 * 28 * 128 * 2 + 16, stream, p);
     }
+    return;
+  }
+  if (p.f16 && p.w2) {   // dtype f16-w2: exact recurrent weights (hi + lo), sixteen-row workgroups for every row of the padded batch
+    hipLaunchKernelGGL(lstm16w2_kernel, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
     return;
   }
   if (p.f16) {

@@ -21,7 +21,7 @@ def _is_torch_cuda(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and x.is_cuda
 
 
-_DTYPES = {"fp32": _lib.F32, "fp16": _lib.F16, "fp32-split": _lib.F32_SPLIT}
+_DTYPES = {"fp32": _lib.F32, "fp16": _lib.F16, "fp32-split": _lib.F32_SPLIT, "fp16-w2": _lib.F16_W2}
 
 
 def plan_sizes(spec, max_batch, segment_len, n_slots=1, dtype="fp32", max_beam=0):

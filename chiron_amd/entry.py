@@ -133,7 +133,7 @@ def build_parser():
                    help="Basecall on this many GPUs of the node: the command starts one process per GPU itself (reads sharded per "
                         "process, host-side gather into merged.<ext>, per-process CPU affinity); 0 / 1: this process, --device.  "
                         "(torch.distributed.run launches are honoured as before.)")
-    p.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp32-split"],
+    p.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp16-w2", "fp32-split"],
                    help="Engine arithmetic: fp32 (parity path), fp16 (f16 MFMA conv + LSTM, fp32 CTC), fp32-split "
                         "(fp32 values as hi/lo half pairs on the f16 matrix cores).")
     p.add_argument("--no-calibration", dest="no_calibration", action="store_true",

@@ -103,8 +103,13 @@ chiron_status chiron_weights_size(const chiron_model_desc* desc, size_t* n_float
  *             multiplied on the f16 matrix cores as hi*hi + hi*lo + lo*hi with fp32 accumulation (the f16 MFMA rate is
  *             16x the fp32 one on gfx950); recurrence, gates, z, logits and CTC are the fp32 code.  Opt-in: it meets the
  *             same 1e-4 logits bound against the oracle as CHIRON_F32 (tests) but it is not bit-for-bit fp32 MFMA
- *             arithmetic, so the headline benchmark stays on CHIRON_F32.  Population BN only.          */
-typedef enum { CHIRON_F32 = 0, CHIRON_F16 = 1, CHIRON_F32_SPLIT = 2 } chiron_dtype;
+ *             arithmetic, so the headline benchmark stays on CHIRON_F32.  Population BN only.
+ * CHIRON_F16_W2: CHIRON_F16's activations (halves) against EXACT weights: every weight is carried as a hi + lo half pair
+ *             (W = hi + lo to 2^-22) and every product is x*lo + x*hi on the f16 matrix cores, fp32 accumulation; the LSTM
+ *             pre-activations z stay fp32 in memory.  What half precision costs this network is mostly the WEIGHTS'
+ *             rounding (tools/f16_study.py: 10 x the activations'), and no calibration data is needed to avoid it:
+ *             the mode for trained checkpoints when CHIRON_F16's accuracy is not enough.  Population BN only.     */
+typedef enum { CHIRON_F32 = 0, CHIRON_F16 = 1, CHIRON_F32_SPLIT = 2, CHIRON_F16_W2 = 3 } chiron_dtype;
 
 typedef struct {
   int32_t device_id;    /* HIP device ordinal                                 */

@@ -181,6 +181,7 @@ def test_engine_plan_sizes_and_addressing_limits(built):
             plan_sizes(dna, **kw)
         assert ei.value.status == _lib.ERR_OVERFLOW, kw
     assert plan_sizes(dna, 20000, 400, dtype="fp16")["T"] == 400          # halves: twice the rows
+    assert plan_sizes(dna, 4096, 400, dtype="fp16-w2") == plan_sizes(dna, 4096, 400, dtype="fp16")   # the same buffers (z is fp32 in both)
     with pytest.raises(_lib.ChironError) as ei:
         plan_sizes(dna, 0, 400)
     assert ei.value.status == _lib.ERR_INVALID

@@ -58,6 +58,10 @@ if __name__ == "__main__":
         run("DNA_default seg400 jump390 b1100 greedy f16", ca.dna_default_spec(), 400, 390, 1100, 0, dtype="fp16")
         run("DNA_default seg400 jump390 b4096 greedy f32", ca.dna_default_spec(), 400, 390, 4096, 0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "w2":  # f16 activations against exact (hi + lo) weights, at configs[4]'s batch and at the headline's
+        run("DNA_default seg400 jump390 b4096 greedy fp16-w2", ca.dna_default_spec(), 400, 390, 4096, 0, dtype="fp16-w2")
+        run("DNA_default seg400 jump390 b1100 greedy fp16-w2", ca.dna_default_spec(), 400, 390, 1100, 0, dtype="fp16-w2")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "split":  # fp32 values as hi/lo half pairs on the f16 matrix cores
         run("DNA_default seg400 jump390 b1100 greedy fp32-split", ca.dna_default_spec(), 400, 390, 1100, 0, dtype="fp32-split")
         run("DNA_default seg400 jump390 b1100 greedy fp32", ca.dna_default_spec(), 400, 390, 1100, 0)
