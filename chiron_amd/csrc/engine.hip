@@ -277,6 +277,7 @@ struct chiron_engine {
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
   bool w2 = false;     // opts.dtype == CHIRON_F16_W2: an f16 engine (f16 is set too) whose weights are exact hi + lo half pairs -- every GEMM
                        // runs its K-segments twice ([x, x] . [W_hi; W_lo], tiled DMA GEMMs only), z stays fp32, the recurrence is lstm16w2_kernel
+  bool w2_zf16 = false;   // f16-w2, A/B switch CHIRON_W2_ZF16=1: z as halves between projection and recurrence
   bool split = false;  // opts.dtype == CHIRON_F32_SPLIT: fp32 values as hi/lo half pairs on the f16 matrix cores (GEMMs only)
   int lasth_ld = 0;    // elements per lasth row (2H; split: rounded up to whole 32-element blocks)
   int kq = GEMM_BK;    // K padding quantum in elements: one LDS chunk = 128 bytes per row (32 floats / 64 halves)
@@ -933,6 +934,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->maxB = opts->max_batch;
   e->BP = roundup(opts->max_batch, 16);
   e->w2 = opts->dtype == CHIRON_F16_W2;
+  e->w2_zf16 = e->w2 && getenv("CHIRON_W2_ZF16") != nullptr;
   e->f16 = opts->dtype == CHIRON_F16 || e->w2;
   e->split = opts->dtype == CHIRON_F32_SPLIT;
   e->kq = e->f16 ? 2 * GEMM_BK : GEMM_BK;
@@ -1350,7 +1352,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
       g.z_ndir = lp.nproj == 1 ? 2 : 1;
       g.z_dir0 = lp.nproj == 1 ? 0 : pj;
       g.z_seq_len = s->seq;
-      g.z_f16 = (e->f16 && !e->w2) ? 1 : 0;
+      g.z_f16 = (e->f16 && (!e->w2 || e->w2_zf16)) ? 1 : 0;
       const double ndir = lp.nproj == 1 ? 2.0 : 1.0;
       // layer 0 reads the CNN features (K = 256: its own kernel instantiation), the other layers the recurrent output
       Prof pr(e, s, l == 0 ? PN_PROJ0 : PN_PROJ, 2.0 * B * T * (double)lp.in_w * 4 * H * ndir, 4.0 * B * T * (lp.in_w + ndir * zc));
@@ -1400,7 +1402,7 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     r.fixed_roles = e->lstm_fixed_roles ? 1 : 0;
     r.group0 = 0;
     r.f16 = e->f16 ? 1 : 0;
-    r.w2 = e->w2 ? 1 : 0;
+    r.w2 = e->w2 ? (e->w2_zf16 ? 2 : 1) : 0;
     if (e->calib && e->f16) {
       // x rows of the layer's kernels: the means of the layer's input (features: batch-major rows; lasth: time-major)
       for (int pj = 0; pj < lp.nproj; ++pj) {

@@ -865,6 +865,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm32s_kernel(const LstmParam
 // (14 MFMAs of 16 cycles), z read as fp32 (the projection of this dtype does not round it), the output written as halves for the
 // next layer's projection / the FC head.  A row's bits do not depend on the batch it travels in.
 // ---------------------------------------------------------------------------------------------------------
+template <bool ZH>   // ZH: z arrives as halves (A/B switch CHIRON_W2_ZF16: half the z traffic, z rounded to 11 bits)
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16w2_kernel(const LstmParams p) {
   __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * HW16];
   __shared__ __attribute__((aligned(16))) float xf[W16_NW * W16_NT * W16_XF];
@@ -902,8 +903,8 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16w2_kernel(const LstmPara
 
   const unsigned outw = p.ndir * p.H;
   const unsigned zcols = 4 * p.H;
-  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;        // floats between consecutive steps
-  const unsigned zlane_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 4 * tile0 + u) * 4) * 4;   // bytes; + 64 per tile
+  const unsigned zstep = (p.BP >> 2) * p.ndir * zcols * 4;        // elements between consecutive steps
+  const unsigned zlane_b = ((((g16 * 4 + q) * p.ndir + dir) * zcols + gp * p.H + 4 * tile0 + u) * 4) * (ZH ? 2 : 4);   // bytes; + 64 (32) per tile
   const unsigned ostep = p.BP * outw;
   const unsigned olane = brow * outw + dir * p.H + 4 * tile0 + u;  // + 4 per tile
   const int hw = tile0 * 64 + row * 4 + u;                          // + 64 per tile
@@ -915,13 +916,23 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16w2_kernel(const LstmPara
   float c[W16_NT] = {0.f, 0.f, 0.f, 0.f}, hprev[W16_NT] = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
   for (int s = 0; s < maxlen; ++s) {
-    const float* zs = p.z + (size_t)s * zstep;   // wave-uniform
     f32x4 zv[W16_NT];
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zv[0]) : "v"(zlane_b), "s"(zs) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(zv[1]) : "v"(zlane_b), "s"(zs) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=v"(zv[2]) : "v"(zlane_b), "s"(zs) : "memory");
-    if (nt == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192" : "=v"(zv[3]) : "v"(zlane_b), "s"(zs) : "memory");
-    else zv[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x4 zh[W16_NT];
+    if (ZH) {
+      const _Float16* zs = reinterpret_cast<const _Float16*>(p.z) + (size_t)s * zstep;   // wave-uniform
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(zh[0]) : "v"(zlane_b), "s"(zs) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, %2 offset:32" : "=v"(zh[1]) : "v"(zlane_b), "s"(zs) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, %2 offset:64" : "=v"(zh[2]) : "v"(zlane_b), "s"(zs) : "memory");
+      if (nt == 4) asm volatile("global_load_dwordx2 %0, %1, %2 offset:96" : "=v"(zh[3]) : "v"(zlane_b), "s"(zs) : "memory");
+      else zh[3] = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    } else {
+      const float* zs = p.z + (size_t)s * zstep;   // wave-uniform
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(zv[0]) : "v"(zlane_b), "s"(zs) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(zv[1]) : "v"(zlane_b), "s"(zs) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=v"(zv[2]) : "v"(zlane_b), "s"(zs) : "memory");
+      if (nt == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192" : "=v"(zv[3]) : "v"(zlane_b), "s"(zs) : "memory");
+      else zv[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     const f16x4* hb = reinterpret_cast<const f16x4*>(hbuf + cur * HW16) + lane;
     f16x4 hv[W16_KS];
 #pragma unroll
@@ -938,7 +949,13 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16w2_kernel(const LstmPara
         for (int ks = 0; ks < W16_KS; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(hv[ks], wh[n][ks], acc[n], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    if (ZH) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(zh[0]), "+v"(zh[1]), "+v"(zh[2]), "+v"(zh[3]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+      for (int n = 0; n < W16_NT; ++n) zv[n] = (f32x4){(float)zh[n][0], (float)zh[n][1], (float)zh[n][2], (float)zh[n][3]};
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    }
     const bool act = s < lenr;
     const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
 #pragma unroll
@@ -1656,7 +1673,10 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
     return;
   }
   if (p.f16 && p.w2) {   // dtype f16-w2: exact recurrent weights (hi + lo), sixteen-row workgroups for every row of the padded batch
-    hipLaunchKernelGGL(lstm16w2_kernel, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    if (p.w2 == 2)
+      hipLaunchKernelGGL(lstm16w2_kernel<true>, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
+    else
+      hipLaunchKernelGGL(lstm16w2_kernel<false>, dim3((p.BP / 16) * p.ndir), dim3(64 * W16_NW), 0, stream, p);
     return;
   }
   if (p.f16) {
