@@ -37,6 +37,7 @@ cp "$OUT/bench_default_1.json" "$OUT/bench_default.json"
 python tools/bench_configs.py > "$OUT/secondary.jsonl" 2> "$OUT/secondary.err"
 python tools/bench_configs.py f16 >> "$OUT/secondary.jsonl" 2>> "$OUT/secondary.err"
 python tools/bench_configs.py split >> "$OUT/secondary.jsonl" 2>> "$OUT/secondary.err"
+python tools/bench_configs.py w2 >> "$OUT/secondary.jsonl" 2>> "$OUT/secondary.err"
 
 # 5. end to end through the host pipeline (synthetic reads x 100k samples -> FASTQ tree): .signal input, fast5 input on the
 #    direct path, fast5 through the reference's two passes; greedy and the default beam 30; behind the fp16 engine at batch 4096
@@ -47,6 +48,7 @@ python tools/e2e_bench.py 512 30 - fp32 1100 signal >> "$OUT/e2e.txt" 2>> "$OUT/
 python tools/e2e_bench.py 512 30 - fp32 1100 fast5 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
 python tools/e2e_bench.py 2048 0 - fp16 4096 signal >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
 python tools/e2e_bench.py 2048 0 - fp16 4096 fast5 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
+python tools/e2e_bench.py 2048 0 - fp16-w2 4096 fast5 >> "$OUT/e2e.txt" 2>> "$OUT/e2e.err"
 
 # 5b. the beam-search kernel on its own: engine logits (flat posteriors) and trained-model-like peaked posteriors, kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/beam" -o beam -- python tools/beam_peaked.py 1100 > "$OUT/${R}_beam_kernel.txt" 2> "$OUT/beam.err"
