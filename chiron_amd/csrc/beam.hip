@@ -459,6 +459,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         if (chs[c] > lane) cafter |= 1u << c;     // the child is a branch the walk reaches later
       }
       bool passed = false, dead = false;
+      bool any_event = false;
       while (true) {
         const bool br = passed || (!dead && (!full || e_tot > botv));
         unsigned cnd = cfin;                      // candidates that would enter the leaves now
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         const unsigned ev = br ? (pend & ~act & (cnd | rst)) : 0u;
         const unsigned long long evm = __ballot(ev != 0u);
         if (evm == 0ull) break;
+        any_event = true;
         const int evc = __builtin_ctz(ev | 16u);
         const int i = __builtin_ctzll(evm);
         const int c = rli(evc, i);
@@ -525,6 +527,18 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         }
       }
 
+      // ---- a QUIET frame: the walk had no event (no leaf inserted, no old probability reset) and the carried entries are still in
+      //      descending order (equal totals keep their slots: the ranking below breaks ties by slot).  Then the ranking is the
+      //      identity, nobody's relatives move, no node is created: the next beam is this one with its three probabilities updated.
+      //      On a trained model's blank-dominated posteriors that is most frames (84 % quiet, 61 % also in order at W = 30); on flat
+      //      posteriors it costs one neighbour shuffle and a ballot per frame.
+      if (!any_event) {
+        const float nxt = __shfl(l_tot, (lane + 1) & 63);
+        if (__ballot(lane + 1 < nL && !(l_tot >= nxt)) == 0ull) {
+          if (lane < nb) e_tot = l_tot, e_blk = l_blk, e_lab = l_lab;
+          continue;
+        }
+      }
       // ---- P3: trie bookkeeping, rank the leaves (descending total), permute into rank order
       *reinterpret_cast<int4*>(chupd + 4 * lane) = make_int4(-1, -1, -1, -1);
       csu[lane] = 0u;
@@ -814,6 +828,7 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
         if (chs[c] > hl) cafter |= 1u << c;
       }
       bool passed = false, dead = false;
+      bool any_event = false;   // of either window
       while (true) {
         const bool br = passed || (!dead && (!full || e_tot > botv));
         unsigned cnd = cfin;
@@ -826,6 +841,7 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
         const unsigned ev = br ? (pend & ~act & (cnd | rst)) : 0u;
         const unsigned long long evm = __ballot(ev != 0u);
         if (evm == 0ull) break;
+        any_event = true;
         const unsigned evh = pick((unsigned)evm, (unsigned)(evm >> 32));
         const bool hev = evh != 0u;                                  // this half has an event in this iteration
         const int i = __builtin_ctz(evh | 0x80000000u);              // its branch (slot in the half)
@@ -873,6 +889,14 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
         }
       }
 
+      // ---- a quiet frame of BOTH windows (see beam64_kernel): no event, carried entries still in order -> only the probabilities move
+      if (!any_event) {
+        const float nxt = __shfl(l_tot, hb + ((hl + 1) & 31));
+        if (__ballot(hl + 1 < nL && !(l_tot >= nxt)) == 0ull) {
+          if (hl < nb) e_tot = l_tot, e_blk = l_blk, e_lab = l_lab;
+          continue;
+        }
+      }
       // ---- P3
       *reinterpret_cast<int4*>(chupd + 4 * lane) = make_int4(-1, -1, -1, -1);
       csu[lane] = 0u;
