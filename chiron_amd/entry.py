@@ -134,7 +134,8 @@ def build_parser():
                         "process, host-side gather into merged.<ext>, per-process CPU affinity); 0 / 1: this process, --device.  "
                         "(torch.distributed.run launches are honoured as before.)")
     p.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp16-w2", "fp32-split"],
-                   help="Engine arithmetic: fp32 (parity path), fp16 (f16 MFMA conv + LSTM, fp32 CTC), fp32-split "
+                   help="Engine arithmetic: fp32 (parity path), fp16 (f16 MFMA conv + LSTM, fp32 CTC), fp16-w2 (fp16's activations against "
+                        "exact hi + lo weights: the f16 mode for trained checkpoints), fp32-split "
                         "(fp32 values as hi/lo half pairs on the f16 matrix cores).")
     p.add_argument("--no-calibration", dest="no_calibration", action="store_true",
                    help="--dtype fp16: skip the bias correction for the weights' rounding to halves (Engine.calibrate on a fixed synthetic "

@@ -1570,6 +1570,38 @@ def test_chiron_call_cli_on_fast5_folder(tmp_path):
             assert "U" in open(os.path.join(trees[0], "result", "read1.fastq")).read().split("\n")[1]
 
 
+def test_chiron_call_cli_dtype_f16_w2(tmp_path):
+    """`chiron call --dtype fp16-w2` on the five example fast5 (synthetic weights): the same file tree as the fp32 run, every read's
+    raw signal identical, and its consensus the glue vote over the greedy decode of an fp16-w2 engine's own logits (the CLI adds
+    nothing dtype-specific: no calibration for this dtype)."""
+    import json
+    import shutil
+    from chiron_amd import assembly, entry, signal_io, eval as ce
+    from oracle import ctc_oracle
+    ex = os.path.join(GOLDEN, "example_dna")
+    digest = json.load(open(os.path.join(ex, "raw_digest.json")))
+    inp = tmp_path / "fast5"
+    inp.mkdir()
+    for name in digest:
+        shutil.copy(os.path.join(ex, name + ".fast5"), str(inp / (name + ".fast5")))
+    out = str(tmp_path / "out")
+    model = os.path.join(os.path.dirname(os.path.abspath(ca.__file__)), "model", "DNA_default")
+    entry.main(["call", "-i", str(inp), "-o", out, "-m", model, "-p", "dna-pre", "-b", "100", "--beam", "0",
+                "--synthetic-weights", "--dtype", "fp16-w2"])
+    spec, w, _ = ca.load_model(model, allow_synthetic=True)
+    with ca.Engine(spec, w, max_batch=100, segment_len=400, dtype="fp16-w2") as eng:
+        for name in digest:
+            fq = open(os.path.join(out, "result", name + ".fastq")).read().split("\n")
+            assert fq[0] == "@" + name and len(fq[1]) == len(fq[3]) > 0 and set(fq[1]) <= set("ACGT")
+            ds = signal_io.read_data_for_eval(os.path.join(out, "raw", name + ".signal"), 0, 390, 400)
+            logits = np.concatenate([eng.infer(ds.event[i:i + 100], ca.seq_len_for_engine(ds.event_length[i:i + 100], 1.0),
+                                               want_logits=True).logits for i in range(0, ds.reads_n, 100)])
+            rows, _ = ctc_oracle.greedy_decode(logits, ds.event_length)
+            bp = [ce.index2base(r) for r in rows if len(r)]
+            cons = assembly.simple_assembly(bp, 390 / 400, kernal="glue")
+            assert ce.index2base(np.argmax(cons, axis=0)) == fq[1], name
+
+
 def test_chiron_call_rna_mode_on_the_reference_rna_example(tmp_path):
     """`chiron call --mode rna` on the reference's own RNA example (chiron/example_data/RNA, five single-read fast5; fixture
     tests/golden/example_rna with the digest of their raw signals) with model/RNA_default -- the shipped RNA topology (k = 13 /
