@@ -980,6 +980,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
                                        : __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][j], a[mi][j], c, 0, 0, 0);
                   }
               }
+#if CHIRON_SENS & 4096
+              // timing experiment (with bit 32: no epilogue): what a second accumulator set would buy -- the previous tile's 20 stores
+              // trickle through this tile's main loop, one per k-group, instead of standing between two tiles (the data is a fragment
+              // register: garbage, same instruction stream and the same z traffic)
+              if (ZOUT && FS && have_prev && C * 4 + g < 4 * NNI) {
+                const int sq = (C * 4 + g) / NNI, sni = (C * 4 + g) % NNI;
+                const unsigned gstr = (unsigned)p.z_dirs_total * p.z_cols * 4;
+                float* o = p.out + (unsigned)((pm0 + wave * 32 + 8 * sq + 4 * kh) >> 2) * gstr + (unsigned)(p.z_dir0 * p.z_cols + pn0 + li) * 4 + sni * 128;
+                if (pm0 + wave * 32 + 8 * sq + 4 * kh < p.M) *reinterpret_cast<f32x4*>(o) = a[0];
+              }
+#endif
             }
           }
           }

@@ -11,7 +11,8 @@
 //                       2 Winograd without input transform, 4 without output transform (wino.hip), 8 recurrence with half of its
 //                       MFMAs (lstm.hip), 16 DMA GEMM with half of its MFMAs, 32 the projection (ZOUT) form without its epilogue, 64 the
 //                       convolution form without its epilogue, 1024 cycle counters (per-chunk barrier waits, epilogue, whole
-//                       tiles) printed by four workgroups (gemm.hip), 2048 the same for the F(4,3) kernel (wino.hip)
+//                       tiles) printed by four workgroups (gemm.hip), 2048 the same for the F(4,3) kernel (wino.hip), 4096 (with 32) the projection's 20 stores
+//                       spread over the next tile's main loop: what a second accumulator set would buy (gemm.hip)
 //   CHIRON_W32_VARIANT  lstm32w_kernel: 1 no gate math, 2 no MFMAs, 3 no transpose
 //   CHIRON_F16F_VARIANT lstm16f_kernel, bit mask: 1 no gate math, 2 no MFMAs, 4 no output stores, 8 no x prefetch, 16 no x tile
 //                       reads, 32 no h tile reads, 64 no h tile writes
