@@ -401,7 +401,7 @@ def f16_config(spec, weights, x_dev, s_dev, ref32, device_id, dtype="fp16"):
     activations against exact (hi + lo) weights -- the mode for trained checkpoints (include/chiron_amd.h CHIRON_F16_W2)."""
     import torch
     import chiron_amd as ca
-    B16, steps = 4096, 6
+    B16, steps = 4096, (6 if dtype == "fp16-w2" else 16)   # (6 steps of 7 ms were at the mercy of one slow launch: 7.3 .. 8.6 ms per batch run to run)
     reps = -(-B16 // BATCH)
     x = torch.cat([x_dev[i % len(x_dev)] for i in range(reps)])[:B16].contiguous()
     sl = torch.cat([s_dev[i % len(s_dev)] for i in range(reps)])[:B16].contiguous()
