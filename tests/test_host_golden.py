@@ -89,6 +89,11 @@ def test_batch_packer_H5_toy_stream():
     assert np.array_equal(batches[3].x[2], batches[3].x[0]) and np.array_equal(batches[3].x[3], batches[3].x[1])
     assert batches[3].seq_len.tolist() == [2, 1, 2, 1]
     assert batches[0].seq_len.tolist() == [2, 2, 1, 2] and batches[0].seq_len.dtype == np.int32
+    # the pipeline walks a batch's per-read runs; the reference's per-row tags above are their expansion, and back
+    assert batches[0].runs == [("a", 0, 3, 0), ("b", 3, 1, 0)] and batches[3].runs == [("c", 0, 2, 0)]
+    for b in batches:
+        again = ce.Batch.from_tags(b.x, b.seq_len, b.fname, b.index, b.n_valid)
+        assert again.runs == b.runs and again.fname.tolist() == b.fname.tolist() and again.index.tolist() == b.index.tolist()
 
 
 def test_seq_len_round_half_even():
