@@ -184,6 +184,11 @@ __device__ __forceinline__ void gemm_epilogue_zrows_t(const GemmParams& p, f32x1
     for (int r = 0; r < 4; ++r) v[r] = (elem_t)acc[0][ni][4 * q + r];
     return v;
   };
+  // z is written once and read once, a whole projection later (1.4 GB per launch: no cache holds it): the whole-vector stores carry
+  // the non-temporal hint.  +0.2 .. 0.4 % headline in three same-box A/B runs (profiles/r04_gemm_epilogue_ab.txt 11); the same hint
+  // on the convolutions' outputs, the recurrence's z loads and outputs, Winograd's and the streaming kernel's stores costs 0 .. 0.8 %
+  // (their consumers find them in the L2 / MALL).
+  auto zst = [&](elem_t* ptr, const vec_t& v) { __builtin_nontemporal_store(v, reinterpret_cast<vec_t*>(ptr)); };
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     // one register quad at a time: with the four quads' addresses and conversions scheduled together the epilogue, not the
@@ -197,7 +202,7 @@ __device__ __forceinline__ void gemm_epilogue_zrows_t(const GemmParams& p, f32x1
     if (all_fwd) {
       elem_t* const o = og + (unsigned)t * per_t;
 #pragma unroll
-      for (int ni = 0; ni < NNI; ++ni) *reinterpret_cast<vec_t*>(o + ni * 128) = vec(ni, q);
+      for (int ni = 0; ni < NNI; ++ni) zst(o + ni * 128, vec(ni, q));
       continue;
     }
     const int4 len = *reinterpret_cast<const int4*>(p.z_seq_len + b);
@@ -207,7 +212,7 @@ __device__ __forceinline__ void gemm_epilogue_zrows_t(const GemmParams& p, f32x1
       if (t < l0) {
         elem_t* const o = og + (unsigned)(l0 - 1 - t) * per_t;
 #pragma unroll
-        for (int ni = 0; ni < NNI; ++ni) *reinterpret_cast<vec_t*>(o + ni * 128) = vec(ni, q);
+        for (int ni = 0; ni < NNI; ++ni) zst(o + ni * 128, vec(ni, q));
       }
       continue;
     }
