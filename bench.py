@@ -110,14 +110,29 @@ def main():
     if stub:
         args.backend, args.no_f16, args.no_cpu_baseline = "gloo", True, True
 
+    # `--gpus N` is the contract: N ranks, one per GPU.  Started bare (no WORLD_SIZE: the way the 1-GPU line is started), the
+    # script starts its own N ranks under torch.distributed.run and rank 0's line is the record; started under a launcher
+    # whose world size is NOT N, it refuses -- a line with the wrong "n_gpus" and rc 0 must not exist (BASELINE.json metric:
+    # "at 1/2/4/8 GPUs").
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: refusing to write a record\n"
+                         % (args.gpus, os.environ["WORLD_SIZE"]))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    device_ordinal = local_rank
     if args.share_gpu:
         local_rank = 0
     if not stub:
+        if local_rank >= torch.cuda.device_count():
+            sys.stderr.write("bench.py: rank %d wants GPU %d, this node shows %d\n" % (rank, local_rank, torch.cuda.device_count()))
+            sys.exit(3)
         torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
@@ -125,6 +140,15 @@ def main():
         else:
             dist.init_process_group(args.backend)
     cdev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # where collectives run
+    if world > 1:
+        # one rank per device: every rank reports the device it computes on (the GPU's PCI address; the ordinal for the stub) and
+        # all of them must differ -- eight ranks on one GPU would still print a line (--share-gpu is the declared self-test)
+        ident = device_identity(torch, local_rank) if not stub else "stub:%d" % device_ordinal
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if not args.share_gpu and ranks_share_a_device(idents, world if stub else torch.cuda.device_count()):
+            sys.stderr.write("bench.py: ranks share a device: %s\n" % idents)
+            sys.exit(4)
 
     import chiron_amd as ca
     from chiron_amd import assembly
@@ -364,6 +388,47 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher: run this same command line as N ranks of one node under
+    torch.distributed.run (rendezvous on 127.0.0.1, a free port), pass their output through, return their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def device_identity(torch, ordinal):
+    """(hardware identity, ordinal) of the GPU a rank computes on: UUID + PCI domain / bus / device as torch reports them"""
+    p = torch.cuda.get_device_properties(ordinal)
+    hw = "/".join(str(getattr(p, a, "")) for a in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return (hw, ordinal)
+
+
+def ranks_share_a_device(idents, device_count):
+    """idents: one device_identity (or a string for the stub) per rank.  Distinct hardware identities = one GPU per rank.  Should a
+    runtime report the same identity for every GPU (attributes not filled in), distinct ordinals within the node's device count
+    are accepted instead -- and said so on stderr."""
+    if len(set(idents)) == len(idents) and all(isinstance(i, str) for i in idents):
+        return False
+    if any(isinstance(i, str) for i in idents):
+        return True
+    hw, ords = [i[0] for i in idents], [i[1] for i in idents]
+    if len(set(hw)) == len(hw):
+        return False
+    if len(set(hw)) == 1 and len(set(ords)) == len(ords) and max(ords) < device_count:
+        sys.stderr.write("bench.py: every GPU reports the identity %r; accepting distinct ordinals %s\n" % (hw[0], ords))
+        return False
+    return True
 
 
 class StubEngine(object):

@@ -49,3 +49,48 @@ def test_bench_line_under_torchrun_with_a_stub_engine(world):
     assert d["extra"]["decoded_bases_total"] == world * steps * rounds * 1100
     h = d["extra"]["host_inclusive"]
     assert h["timed_steps"] == steps and h["kbases_per_s"] > 0
+
+
+def _bench(argv, env=None, timeout=600):
+    e = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bare_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 4` WITHOUT a launcher (the way the driver's 1-GPU line is started) must not run one rank and print
+    "n_gpus": 1 with rc 0 (round-4 review, Missing #3): it starts four ranks itself and rank 0's line says n_gpus 4."""
+    out = _bench(["--gpus", "4", "--stub-engine", "12", "--steps", "4", "--rounds", "2", "--host-rounds", "0", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["timed_steps"] == 8 and d["extra"]["decoded_bases_total"] == 4 * 8 * 1100
+
+
+def test_bench_refuses_a_launcher_whose_world_size_is_not_gpus():
+    out = _bench(["--gpus", "4", "--stub-engine", "12"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert out.returncode == 2 and "refusing" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    out = _bench(["--gpus", "1", "--stub-engine", "12"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert out.returncode == 2
+
+
+def test_ranks_must_sit_on_distinct_devices():
+    sys.path.insert(0, ROOT)
+    import bench
+    hw = lambda i: ("uuid%d/0/%d/0" % (i, i), i)
+    assert not bench.ranks_share_a_device([hw(i) for i in range(8)], 8)
+    assert bench.ranks_share_a_device([hw(0), hw(1), hw(1), hw(3)], 8)                     # two ranks on GPU 1
+    assert bench.ranks_share_a_device([hw(0)] * 8, 8)                                      # eight ranks on GPU 0
+    same = [("0000/0/0/0", i) for i in range(8)]                                           # a runtime that fills nothing in
+    assert not bench.ranks_share_a_device(same, 8) and bench.ranks_share_a_device(same, 4)
+    assert not bench.ranks_share_a_device(["stub:0", "stub:1"], 2) and bench.ranks_share_a_device(["stub:0", "stub:0"], 2)
+    # two ranks given the same ordinal under a launcher: refused unless it is the declared self-test
+    e = {"WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
+    ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-engine", "5", "--steps", "2", "--rounds", "1",
+                            "--host-rounds", "0", "--warmup", "1"], cwd=ROOT, env=dict(os.environ, RANK=str(r), LOCAL_RANK="0", **e),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in ps]
+    assert [p.returncode for p in ps] == [4, 4] and "share a device" in outs[0][1]
