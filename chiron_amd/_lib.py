@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CHIRON_AMD_LIB") or os.path.join(_HERE, "csrc", "libc
 MAX_BLOCKS = 8
 CLASSES = 5
 
-ABI_VERSION = 5      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
+ABI_VERSION = 6      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
@@ -97,6 +97,7 @@ SYMBOLS = [
     ("chiron_fast5_fastq", C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]),
     ("chiron_write_signal_text", C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p]),
     ("chiron_last_error", C.c_char_p, []),
+    ("chiron_device_pci_bus_id", C.c_int, [C.c_int32, C.c_char_p, C.c_size_t]),
     ("chiron_abi_version", C.c_int32, []),
     ("chiron_build_flags", C.c_uint32, []),
 ]
@@ -137,13 +138,19 @@ def load():
                           "(hipcc --offload-arch=gfx950). chiron_amd has no CPU fallback." % LIB_PATH)
     _init_torch_runtime_first()
     lib = C.CDLL(LIB_PATH)
+    # the version first: a stale library lacks the newer symbols, and "rebuild it" is the message to give, not an AttributeError
+    try:
+        lib.chiron_abi_version.restype = C.c_int32
+        have = lib.chiron_abi_version()
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise ImportError("%s has ABI version %s, this binding was written against %d: rebuild it "
+                          "(python -c 'import __graft_entry__ as g; g.build()')" % (LIB_PATH, have, ABI_VERSION))
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.chiron_abi_version() != ABI_VERSION:
-        raise ImportError("%s has ABI version %d, this binding was written against %d: rebuild it"
-                          % (LIB_PATH, lib.chiron_abi_version(), ABI_VERSION))
     if (lib.chiron_build_flags() & BUILD_TIMING) and os.environ.get("CHIRON_ALLOW_TIMING_BUILD") != "1":
         raise ImportError("%s is a TIMING build (a kernel variant with parts switched off, csrc/timing_variants.h): its results "
                           "are garbage.  Measurement tools set CHIRON_ALLOW_TIMING_BUILD=1; nothing else may load it." % LIB_PATH)

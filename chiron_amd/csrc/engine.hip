@@ -66,6 +66,18 @@ void mark_timing_build(const char* source) {
 }  // namespace chiron
 extern "C" uint32_t chiron_build_flags(void) { return g_timing_build ? CHIRON_BUILD_TIMING : 0u; }
 
+extern "C" chiron_status chiron_device_pci_bus_id(int32_t device_id, char* out, size_t cap) {
+  if (!out || cap < 16) return chiron::set_error(CHIRON_ERR_INVALID, "chiron_device_pci_bus_id: buffer of at least 16 bytes needed");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return chiron::set_error(CHIRON_ERR_DEVICE, "no HIP device");
+  if (device_id < 0 || device_id >= n) return chiron::set_error(CHIRON_ERR_INVALID, "device %d of %d", device_id, n);
+  hipError_t err = hipDeviceGetPCIBusId(out, (int)cap, device_id);
+  if (err != hipSuccess) return chiron::set_error(CHIRON_ERR_DEVICE, "hipDeviceGetPCIBusId: %s", hipGetErrorString(err));
+  for (char* c = out; *c; ++c)
+    if (*c >= 'A' && *c <= 'F') *c += 'a' - 'A';   // sysfs spells PCI addresses in lower case
+  return CHIRON_OK;
+}
+
 static int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 // TF 'SAME' padding: out = ceil(W/s), pad_total = max((out-1)s + k - W, 0), left = total/2
@@ -163,6 +175,7 @@ struct CalibCtx {
   double* dev_sums = nullptr;  // [max_records][256]
   size_t max_records = 0;
   std::vector<CalibRecord> rec;
+  int skipped = 0;             // inputs that could not be measured (more than 256 channels, or more records than max_records)
 };
 
 struct BlockPlan {
@@ -170,7 +183,7 @@ struct BlockPlan {
   int c_in = 0, c = 0, k = 0, stride = 1, left = 0;
   int t_in = 0, t_out = 0;
   float *lift_a = nullptr, *lift_b = nullptr;  // lift: conv2a folded scale/shift
-  float* res_a = nullptr;                      // lift: branch1 folded scale
+  float *res_a = nullptr, *res_b = nullptr;    // lift: branch1 folded scale and its own folded shift (kernels.h res_b)
   // lift, population BN: conv2a + conv2b as a piecewise-linear table of the signal value (pwl.hip)
   float *pwl_bp = nullptr, *pwl_ref = nullptr, *pwl_tab = nullptr, *pwl_shift = nullptr;
   int pwl_nbp = 0;
@@ -504,12 +517,14 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       }
     }
     if (bp.lift) {
-      std::vector<float> la(cop, 0.f), lb(cop, 0.f), ra(Npad, 0.f);
+      std::vector<float> la(cop, 0.f), lb(cop, 0.f), ra(Npad, 0.f), rb(Npad, 0.f);
       for (int c = 0; c < co; ++c) {
         la[c] = W2a[c] * f2a.inv[c];
         lb[c] = f2a.sh[c];
         ra[c] = W1[c] * f1.inv[c];
+        rb[c] = e->f16 ? 0.f : f1.sh[c];   // the f16 engines keep round 4's arithmetic (shift folded): halves' rounding dominates there
       }
+      if ((st = dev_upload(e, &bp.res_b, rb))) return st;
       if ((st = dev_upload(e, &bp.lift_a, la))) return st;
       if ((st = dev_upload(e, &bp.lift_b, lb))) return st;
       if ((st = dev_upload(e, &bp.res_a, ra))) return st;
@@ -560,12 +575,13 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
         if ((st = dev_upload(e, &bp.pwl_tab, tab))) return st;
         if ((st = dev_upload(e, &bp.pwl_shift, sh2))) return st;
       }
-      // conv2c with the branch1 shift folded into the epilogue shift
+      // conv2c; the signal branch (scale res_a, shift res_b) is evaluated by the epilogue as one fmaf and added to the finished sum
+      // (batch-statistics BN: both fold to 1 / 0 here and the branch is normalised by bn_batch.hip)
       const int K = cop;
       std::vector<float> Wt((size_t)Npad * K, 0.f), sh(Npad, 0.f);
       for (int n = 0; n < co; ++n) {
         for (int c = 0; c < co; ++c) Wt[(size_t)n * K + c] = W2c[(size_t)c * co + n] * f2c.inv[n];
-        sh[n] = f2c.sh[n] + f1.sh[n];
+        sh[n] = e->f16 ? f2c.sh[n] + f1.sh[n] : f2c.sh[n];
       }
       if ((st = upload_gemm(e, &bp.gc, Wt, sh, co, Npad, K))) return st;
     } else {
@@ -1057,7 +1073,11 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
 static void calib_measure(chiron_engine* e, const float* shift, int k0, const void* src, long rows, int ld, int col0, int cin, int BP, int B,
                           int lstm_layer, int lstm_dir, int lstm_part, hipStream_t stream) {
   CalibCtx* c = e->calib;
-  if (!c || c->rec.size() >= c->max_records || cin > 256) return;
+  if (!c) return;
+  if (c->rec.size() >= c->max_records || cin > 256) {   // a partially applied correction must not pass silently (advisor, round 4)
+    ++c->skipped;
+    return;
+  }
   CalibRecord r{shift, k0, cin, lstm_layer, lstm_dir, lstm_part, BP > 0 ? (double)(rows / BP) * B : (double)rows, c->rec.size()};
   launch_colsum_f16(src, rows, ld, col0, cin, BP, B, c->dev_sums + r.slot * 256, stream);
   c->rec.push_back(r);
@@ -1249,6 +1269,7 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
       g.sig = sig;
       g.L = e->L;
       g.res_a = b.res_a;
+      g.res_b = b.res_b;
       g.res_stride = b.stride;
       g.out = bufA;
       g.ldo = b.c;
@@ -1701,9 +1722,11 @@ extern "C" chiron_status chiron_engine_features(chiron_engine* e, int32_t slot, 
 // the weights to halves costs.
 extern "C" chiron_status chiron_engine_calibrate(chiron_engine* e, const float* x, const int32_t* seq_len, int32_t batch, int32_t iterations) {
   if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
-  if (!x || !seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
-  if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
   if (iterations < 0 || iterations > 16) return fail(CHIRON_ERR_INVALID, "iterations %d", iterations);
+  if (iterations > 0) {     // iterations = 0 only restores the uncorrected shifts: it reads no calibration data
+    if (!x || !seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
+    if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
+  }
   if (!e->f16 || e->w2) return CHIRON_OK;      // fp32 / fp32-split / hi + lo weights are not rounded: nothing to correct
   Slot* s = &e->slots[0];
   for (Slot& sl : e->slots)
@@ -1734,6 +1757,9 @@ extern "C" chiron_status chiron_engine_calibrate(chiron_engine* e, const float* 
     };
     st = run();
     s->net_batch = 0;
+    if (st == CHIRON_OK && ctx.skipped)
+      st = fail(CHIRON_ERR_OVERFLOW, "calibration could not measure %d of the network's inputs (more than 256 channels, or more than %zu "
+                "measured inputs): no correction applied", ctx.skipped, ctx.max_records);
     if (st) {
       resync_tile_counters(s);
       break;

@@ -127,8 +127,9 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
           for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r];
           if (RES) {
             const f32x4 ra4 = *reinterpret_cast<const f32x4*>(p.res_a + n0 + wn * 64 + ni * 32 + 8 * q + 4 * kh);
+            const f32x4 rb4 = *reinterpret_cast<const f32x4*>(p.res_b + n0 + wn * 64 + ni * 32 + 8 * q + 4 * kh);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(sv, ra4[r], v[r]);
+            for (int r = 0; r < 4; ++r) v[r] += fmaf(sv, ra4[r], rb4[r]);
           }
           if (RELU) {
 #pragma unroll
@@ -283,8 +284,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           }
           if (RES) {
             const f32x4 ra4 = *reinterpret_cast<const f32x4*>(p.res_a + n);
+            const f32x4 rb4 = *reinterpret_cast<const f32x4*>(p.res_b + n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(sv, ra4[r], v[r]);
+            for (int r = 0; r < 4; ++r) v[r] += fmaf(sv, ra4[r], rb4[r]);
           }
           if (p.relu) {
 #pragma unroll

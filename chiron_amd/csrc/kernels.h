@@ -75,8 +75,13 @@ struct GemmParams {
   const float* lift_a;
   const float* lift_b;
   // residual synthesised from the signal (res_layer1/branch1: 1x1 conv on the signal + BN):
-  //   + sig[b][t_out*res_stride] * res_a[n]      (its BN offset is folded into shift[])
+  //   + (sig[b][t_out*res_stride] * res_a[n] + res_b[n])
+  // res_b = that branch's own folded BN shift (offset - mean*inv, of the order of -500 * res_a for a raw signal around 500).  It is
+  // NOT folded into shift[]: the branch is evaluated as ONE fmaf whose exact value is small, and added to the finished
+  // accumulator -- inside shift[] it would ride through the whole K chain and every step would round at ITS magnitude
+  // (round 5: 1.3e-6 -> 0.8e-6 rms born in res_layer1 on trained-like weights, profiles/r05_parity_error_structure.txt).
   const float* res_a;
+  const float* res_b;
   int res_stride;
   // output
   float* out;

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
   extern __shared__ __attribute__((aligned(16))) float tiles[];   // [T_D][64 pieces][32 positions][4 floats]
   __shared__ __attribute__((aligned(16))) float shl[T_C];
   __shared__ __attribute__((aligned(16))) float rsl[T_C];
+  __shared__ __attribute__((aligned(16))) float rbl[T_C];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
   if (p.M < 0) tiles[tid] = 0.f;
   if (tid < T_C) shl[tid] = p.shift ? p.shift[tid] : 0.f;
   if (tid < T_C) rsl[tid] = (RES && p.res_a) ? p.res_a[tid] : 0.f;
+  if (tid < T_C) rbl[tid] = (RES && p.res_b) ? p.res_b[tid] : 0.f;
   __syncthreads();
 
   const int ntiles = (p.M + T_ROWS - 1) / T_ROWS;
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
   }
   const float* const bias = shl + 32 * wave + 4 * kh;
   const float* const resa = rsl + 32 * wave + 4 * kh;
+  const float* const resb = rbl + 32 * wave + 4 * kh;
   float* const outp = p.out + 32 * wave + 4 * kh;
   const bool relu = p.relu != 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights are in: from here on vmcnt counts tiles and stores only
@@ -179,9 +182,11 @@ __global__ __launch_bounds__(64 * T_NW, 1) void conv1x1_f32_stream_kernel(const 
       for (int q = 0; q < 4; ++q) {
         f32x4 v = {acc0[4 * q] + acc1[4 * q], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2], acc0[4 * q + 3] + acc1[4 * q + 3]};
         if (RES) {
+          // the signal branch as ONE fmaf (exact value small: sv*a cancels against b), added to the finished sum (kernels.h res_b)
           const f32x4 r4 = *reinterpret_cast<const f32x4*>(resa + 8 * q);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(resb + 8 * q);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaf(sv, r4[r], v[r]);
+          for (int r = 0; r < 4; ++r) v[r] += fmaf(sv, r4[r], b4[r]);
         }
         if (relu) {
 #pragma unroll

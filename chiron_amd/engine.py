@@ -35,7 +35,13 @@ def plan_sizes(spec, max_batch, segment_len, n_slots=1, dtype="fp32", max_beam=0
 
 
 class Engine(object):
-    def __init__(self, spec, weights, max_batch, segment_len, device_id=0, n_slots=1, max_beam=0, dtype="fp32"):
+    def __init__(self, spec, weights, max_batch, segment_len, device_id=0, n_slots=1, max_beam=0, dtype="fp32", calibrate=False):
+        """calibrate (dtype "fp16" only; opt-in, a no-op for every other dtype): apply the bias correction for the weights' rounding to
+        halves on the fixed synthetic calibration batch (calibration_windows) right after creation.  THE one place every entry point
+        -- `chiron call` (eval.py), the serving surface (serve.py), bench.py, direct users -- asks for it, so that the same read
+        decodes to the same string whichever of them built the engine; `self.calibrated` says whether it was applied and `chiron
+        call` records it in <output>/log/engine*.json.  The correction was validated on synthetic trained-like weights and synthetic
+        signal: with a real checkpoint compare both settings on real reads before relying on it."""
         if not isinstance(spec, ModelSpec):
             raise TypeError("spec must be a ModelSpec")
         self._lib = _lib.load()
@@ -61,6 +67,10 @@ class Engine(object):
         self.n_slots = n_slots
         self.device_id = device_id
         self._keep = [None] * n_slots      # keep submitted arrays alive until collect
+        self.dtype = dtype
+        self.calibrated = False
+        if calibrate and dtype == "fp16":
+            self.calibrate()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -162,6 +172,10 @@ class Engine(object):
         """f16 engines: bias correction for the weights' rounding to halves (chiron_engine_calibrate); a no-op for fp32 / fp32-split.
         x [n, segment_len] float32 calibration windows (default: `calibration_windows`, a fixed synthetic squiggle, so that every
         process that builds this engine builds the same one); iterations = 0 restores the uncorrected engine."""
+        if int(iterations) == 0:
+            _lib.check(self._lib.chiron_engine_calibrate(self._h, None, None, 0, 0))
+            self.calibrated = False
+            return
         if x is None:
             x, seq_len = calibration_windows(self.segment_len, min(self.max_batch, 256), self.ratio)
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -170,6 +184,7 @@ class Engine(object):
             raise ValueError("x must be [n, %d] with one seq_len per row" % self.segment_len)
         _lib.check(self._lib.chiron_engine_calibrate(self._h, x.ctypes.data_as(C.c_void_p), seq_len.ctypes.data_as(C.c_void_p),
                                                      x.shape[0], int(iterations)))
+        self.calibrated = self.dtype == "fp16"
 
     def rnn_output(self, slot=0):
         """`lasth` (rnn.py:63-65 / :140-145): the recurrent stack's output [batch, T, 2H] of the batch last run on the (idle) slot."""

@@ -41,13 +41,24 @@ def evaluation(args):
     """entry.py:19-47: extract fast5 -> <out>/raw, then basecall <out>/raw."""
     import os as _os
     n_gpus = int(getattr(args, "gpus", 0) or 0)
-    if n_gpus > 1 and not _os.environ.get("CHIRON_LOCAL_WORLD"):
+    child_vars = [v for v in ("CHIRON_LOCAL_RANK", "CHIRON_LOCAL_WORLD", "CHIRON_BARRIER_DIR") if _os.environ.get(v)]
+    if child_vars and len(child_vars) != 3:
+        # a rank of `chiron call --gpus N` gets all three from its parent; one or two of them is a stale export, and treating
+        # the process as a rank would die later with a KeyError (or, worse, skip the spawn silently)
+        raise RuntimeError("%s set without the other CHIRON_LOCAL_* variables: unset it (only `chiron call --gpus N` sets them, "
+                           "all three, for its own ranks)" % ", ".join(child_vars))
+    if n_gpus > 1 and not child_vars:
         # `chiron call --gpus N`: this process only starts the N ranks (one per GPU, each on its own slice of the host's cores)
         # and waits; the ranks shard the reads, meet at a file barrier and rank 0 gathers merged.<ext> (shard.py)
         from . import shard
         resolve_preset(args)                       # a bad preset / mode fails here, once, not N times
         _os.makedirs(args.output, exist_ok=True)
-        codes = shard.spawn_local_ranks(args.child_argv, n_gpus, args.output, share_gpu=_os.environ.get("CHIRON_SHARE_GPU") == "1")
+        child_argv = getattr(args, "child_argv", None)
+        if child_argv is None:
+            # evaluation(args) called with a Namespace instead of through main(): the ranks need a command line
+            raise ValueError("--gpus %d needs the command line to give its ranks: call chiron_amd.entry.main([...]) or set "
+                             "args.child_argv" % n_gpus)
+        codes = shard.spawn_local_ranks(child_argv, n_gpus, args.output, share_gpu=_os.environ.get("CHIRON_SHARE_GPU") == "1")
         if any(codes):
             raise RuntimeError("chiron call --gpus %d: rank exit codes %s" % (n_gpus, codes))
         return codes

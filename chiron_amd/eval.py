@@ -453,6 +453,21 @@ def _finish_read_in_process(name, flat, seg_len, qs_list, flags, t_start, readin
     return finish_read_flat(name, flat, seg_len, qs_list, argparse.Namespace(**flags), t_start, reading_time)
 
 
+def _record_engine(FLAGS, engine):
+    """<output>/log/engine[.rank<r>].json: what basecalled this output -- dtype, and whether the fp16 bias correction was applied (the
+    same read decodes differently with and without it; the reference's meta/ files keep the reference's format)."""
+    import json
+    try:
+        d = os.path.join(FLAGS.output, "log")
+        os.makedirs(d, exist_ok=True)
+        rank = os.environ.get("CHIRON_LOCAL_RANK", os.environ.get("RANK"))
+        with open(os.path.join(d, "engine%s.json" % (".rank" + rank if rank else "")), "w") as fh:
+            json.dump({"dtype": engine.dtype, "fp16_bias_correction": bool(engine.calibrated), "max_batch": engine.max_batch,
+                       "segment_len": engine.segment_len, "slots": engine.n_slots, "device": engine.device_id}, fh)
+    except OSError:
+        pass
+
+
 def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
     """chiron_eval.py:378-463 on one GPU.  `file_list` restricts the reads this process handles
     (per-read sharding across GPUs).  `fast5_files` (full paths) switches to the direct fast5 path of
@@ -464,11 +479,12 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
         spec, weights, _ = model_mod.load_model(FLAGS.model, allow_synthetic=getattr(FLAGS, "synthetic_weights", False))
         engine = Engine(spec, weights, max_batch=FLAGS.batch_size, segment_len=FLAGS.segment_len,
                         device_id=getattr(FLAGS, "device", 0), n_slots=int(getattr(FLAGS, "slots", 0) or 3), max_beam=FLAGS.beam,
-                        dtype=getattr(FLAGS, "dtype", "fp32"))
-        if getattr(FLAGS, "dtype", "fp32") == "fp16" and not getattr(FLAGS, "no_calibration", False):
-            # bias correction for the weights' rounding to halves (Engine.calibrate): a fixed synthetic calibration batch, so every
-            # rank of a sharded run builds the same engine and a read's output does not depend on which process basecalls it
-            engine.calibrate()
+                        dtype=getattr(FLAGS, "dtype", "fp32"),
+                        # fp16: bias correction for the weights' rounding to halves on a FIXED synthetic calibration batch, so every
+                        # rank of a sharded run builds the same engine and a read's output does not depend on which process
+                        # basecalls it (Engine(calibrate=...) is the one switch of every entry point)
+                        calibrate=not getattr(FLAGS, "no_calibration", False))
+        _record_engine(FLAGS, engine)
     if fast5_files is None:
         files, file_dir = list_inputs(FLAGS.input, getattr(FLAGS, "recursive", False))
         if file_list is not None:

@@ -395,7 +395,9 @@ def start_server(a):
         fd = os.open(a.authkey_file, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
         with os.fdopen(fd, "wb") as f:
             f.write(key)
-    eng = Engine(spec, weights, max_batch=a.batch_size, segment_len=seg, n_slots=a.slots, max_beam=a.beam)
+    # the same dtype / calibration switches as `chiron call`: a read decodes to the same string behind either entry point
+    eng = Engine(spec, weights, max_batch=a.batch_size, segment_len=seg, n_slots=a.slots, max_beam=a.beam, dtype=getattr(a, "dtype", "fp32"),
+                 calibrate=not getattr(a, "no_calibration", False))
     return PredictServer(eng, ("127.0.0.1", a.port), beam_width=a.beam, authkey=key), eng
 
 
@@ -413,6 +415,8 @@ def main(argv=None):
     sp.add_argument("--beam", type=int, default=50)                 # export_test.py beam_width flag
     sp.add_argument("--slots", type=int, default=2)
     sp.add_argument("--synthetic-weights", action="store_true")
+    sp.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp16-w2", "fp32-split"])
+    sp.add_argument("--no-calibration", dest="no_calibration", action="store_true", help="--dtype fp16: as `chiron call --no-calibration`")
     sp.add_argument("--authkey-file", default=None, help="file holding the handshake key; created (0600) with a fresh key when absent")
     cp = sub.add_parser("client")
     cp.add_argument("--authkey-file", default=None, help="the key file the server wrote (or set CHIRON_SERVE_AUTHKEY)")

@@ -8,15 +8,35 @@ import os
 import time
 
 
+def _alive(pid):
+    try:
+        os.kill(int(pid), 0)
+    except (OSError, ValueError):
+        return False
+    try:                                       # a zombie still answers kill(pid, 0): it has exited
+        with open("/proc/%d/stat" % int(pid)) as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except (OSError, IndexError):
+        return True
+
+
 class LocalRanks(object):
     """The ranks of `chiron call --gpus N` (spawn_local_ranks below): the data path needs no collective, so the only thing the
     ranks share is a BARRIER, and a folder of marker files carries it -- no torch.distributed, no RCCL, no port.  Same surface
-    as the three torch.distributed calls run_sharded / entry use (get_rank, get_world_size, barrier, destroy_process_group)."""
+    as the three torch.distributed calls run_sharded / entry use (get_rank, get_world_size, barrier, destroy_process_group).
+    A waiting rank gives up -- and releases its GPU -- when (a) the parent left failed.<r> for a rank that exited non-zero, (b) the
+    parent itself is gone (SIGKILL / OOM: nobody would ever write failed.*), (c) a peer whose pid is on record (pid.<r>, written by
+    every rank at start-up) no longer exists, or (d) CHIRON_BARRIER_TIMEOUT_S (default one hour: the longest a rank may lag behind the
+    others, not the length of the job) has passed."""
 
-    def __init__(self, rank, world, folder, timeout_s=24 * 3600.0):
-        self.rank, self.world, self.folder, self.timeout_s = int(rank), int(world), folder, timeout_s
+    def __init__(self, rank, world, folder, timeout_s=None, parent_pid=None):
+        self.rank, self.world, self.folder = int(rank), int(world), folder
+        self.timeout_s = float(os.environ.get("CHIRON_BARRIER_TIMEOUT_S", 3600.0)) if timeout_s is None else float(timeout_s)
+        self.parent_pid = parent_pid
         self.phase = 0
         os.makedirs(folder, exist_ok=True)
+        with open(os.path.join(folder, "pid.%d" % self.rank), "w") as f:
+            f.write("%d\n" % os.getpid())
 
     def get_rank(self):
         return self.rank
@@ -24,16 +44,29 @@ class LocalRanks(object):
     def get_world_size(self):
         return self.world
 
+    def _peers_gone(self):
+        gone = []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            try:
+                with open(os.path.join(self.folder, "pid.%d" % r)) as f:
+                    pid = f.read().strip()
+            except OSError:
+                continue                       # not started yet
+            if pid and not _alive(pid):
+                gone.append(r)
+        return gone
+
     def barrier(self):
-        """every rank writes barrier.<phase>.<rank> and waits until all `world` markers of the phase exist; a rank that died
-        leaves `failed.<rank>` (spawn_local_ranks' parent writes it) and the others stop waiting."""
+        """every rank writes barrier.<phase>.<rank> and waits until all `world` markers of the phase exist"""
         self.phase += 1
         mine = os.path.join(self.folder, "barrier.%d.%d" % (self.phase, self.rank))
         with open(mine, "w") as f:
             f.write("%d\n" % os.getpid())
         want = ["barrier.%d.%d" % (self.phase, r) for r in range(self.world)]
         t0 = time.time()
-        delay = 0.002
+        delay, checked = 0.002, t0
         while True:
             have = set(os.listdir(self.folder))
             if all(w in have for w in want):
@@ -41,8 +74,16 @@ class LocalRanks(object):
             dead = sorted(n for n in have if n.startswith("failed."))
             if dead:
                 raise RuntimeError("rank(s) %s failed: the barrier cannot complete" % ", ".join(n.split(".")[1] for n in dead))
-            if time.time() - t0 > self.timeout_s:
-                raise RuntimeError("barrier %d timed out after %.0f s" % (self.phase, self.timeout_s))
+            now = time.time()
+            if now - checked > 0.5:            # liveness twice a second: a kill(pid, 0) per peer
+                checked = now
+                if self.parent_pid and not _alive(self.parent_pid):
+                    raise RuntimeError("the process that started the ranks (pid %s) is gone: leaving barrier %d" % (self.parent_pid, self.phase))
+                gone = [r for r in self._peers_gone() if "barrier.%d.%d" % (self.phase, r) not in have]
+                if gone:
+                    raise RuntimeError("rank(s) %s exited before barrier %d" % (", ".join(map(str, gone)), self.phase))
+            if now - t0 > self.timeout_s:
+                raise RuntimeError("barrier %d timed out after %.0f s (CHIRON_BARRIER_TIMEOUT_S)" % (self.phase, self.timeout_s))
             time.sleep(delay)
             delay = min(0.05, delay * 1.5)
 
@@ -50,22 +91,83 @@ class LocalRanks(object):
         pass
 
 
-def rank_cpus(rank, world, cpus=None):
-    """CPU affinity of one local rank: the r-th of `world` contiguous slices of the cores this process may use (a rank's reader
-    and finisher threads then stay on cores next to each other -- one L3 / NUMA neighbourhood on the usual enumeration --
-    instead of migrating over the whole host between eight ranks' threads)."""
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_nodes(world, share_gpu=False, sysfs="/sys"):
+    """NUMA node of the GPU each local rank computes on, or None where it cannot be told: HIP device r -> its PCI address
+    (chiron_device_pci_bus_id: the runtime's ordinal, not /sys/class/drm's card numbering, which also counts other adapters) ->
+    <sysfs>/bus/pci/devices/<address>/numa_node (-1 on a single-node host)."""
+    from . import _lib
+    import ctypes as C
+    try:
+        lib = _lib.load()
+    except (ImportError, OSError):
+        return [None] * world
+    nodes = []
+    for r in range(world):
+        buf = C.create_string_buffer(64)
+        node = None
+        if lib.chiron_device_pci_bus_id(0 if share_gpu else r, buf, 64) == 0:
+            try:
+                with open(os.path.join(sysfs, "bus", "pci", "devices", buf.value.decode(), "numa_node")) as f:
+                    v = int(f.read().strip())
+                node = v if v >= 0 else None
+            except (OSError, ValueError):
+                node = None
+        nodes.append(node)
+    return nodes
+
+
+def node_cpus(sysfs="/sys"):
+    """{NUMA node: [cpu, ...]} of this host"""
+    base = os.path.join(sysfs, "devices", "system", "node")
+    out = {}
+    try:
+        for name in os.listdir(base):
+            if name.startswith("node") and name[4:].isdigit():
+                with open(os.path.join(base, name, "cpulist")) as f:
+                    out[int(name[4:])] = _parse_cpulist(f.read())
+    except OSError:
+        pass
+    return out
+
+
+def rank_cpus(rank, world, cpus=None, gpu_nodes=None, cpus_of_node=None):
+    """CPU affinity of one local rank.  With the NUMA node of every rank's GPU known (gpu_nodes[r], gpu_numa_nodes) and the
+    host's node -> cpus map: the ranks whose GPUs hang off one node share THAT node's allowed cores in contiguous slices -- a rank's
+    pinned staging buffers, its reader / finisher threads and its GPU's PCIe root then sit on one node (round-4 review, Weak #9: the
+    slices used to go by rank index alone).  Without that knowledge (single-node host, no sysfs, no GPU): the r-th of `world`
+    contiguous slices of the allowed cores, as before."""
     cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
     n = len(cpus)
     if world <= 1 or n < world:
         return cpus
+    if gpu_nodes and cpus_of_node and len(gpu_nodes) == world and all(g is not None for g in gpu_nodes):
+        node = gpu_nodes[rank]
+        mine = [c for c in cpus_of_node.get(node, []) if c in set(cpus)]
+        sharers = [r for r in range(world) if gpu_nodes[r] == node]
+        if len(mine) >= len(sharers):
+            i = sharers.index(rank)
+            return mine[i * len(mine) // len(sharers):(i + 1) * len(mine) // len(sharers)]
     lo, hi = rank * n // world, (rank + 1) * n // world
     return cpus[lo:hi]
 
 
-def spawn_local_ranks(argv, n_gpus, output, python=None, share_gpu=False):
+def spawn_local_ranks(argv, n_gpus, output, python=None, share_gpu=False, grace_s=10.0):
     """`chiron call --gpus N`: N child processes of `python -m chiron_amd.entry <argv>`, rank r on GPU r (on GPU 0 with
-    share_gpu: the self-test on a one-GPU box) and on its own slice of the host's cores; CHIRON_LOCAL_RANK / CHIRON_LOCAL_WORLD /
-    CHIRON_BARRIER_DIR tell the child who it is (init_distributed below).  -> list of exit codes (the caller raises)."""
+    share_gpu: the self-test on a one-GPU box) and on the cores next to its GPU; CHIRON_LOCAL_RANK / CHIRON_LOCAL_WORLD /
+    CHIRON_BARRIER_DIR (+ CHIRON_PARENT_PID) tell the child who it is (init_distributed below).  When a rank exits non-zero the
+    others are told (failed.<r>: they leave their next barrier) and, `grace_s` seconds later, terminated if they are still running
+    -- a rank in the middle of a long basecall must not hold its GPU for a job that has already failed.
+    -> list of exit codes (the caller raises)."""
     import shutil
     import subprocess
     import sys
@@ -75,7 +177,7 @@ def spawn_local_ranks(argv, n_gpus, output, python=None, share_gpu=False):
     procs = []
     for r in range(n_gpus):
         env = dict(os.environ, CHIRON_LOCAL_RANK=str(r), CHIRON_LOCAL_WORLD=str(n_gpus), CHIRON_BARRIER_DIR=folder,
-                   LOCAL_WORLD_SIZE=str(n_gpus))
+                   CHIRON_PARENT_PID=str(os.getpid()), LOCAL_WORLD_SIZE=str(n_gpus))
         env.pop("WORLD_SIZE", None)          # the children are not torch.distributed ranks
         pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
@@ -83,12 +185,19 @@ def spawn_local_ranks(argv, n_gpus, output, python=None, share_gpu=False):
             env["CHIRON_SHARE_GPU"] = "1"
         procs.append(subprocess.Popen([python or sys.executable, "-m", "chiron_amd.entry"] + list(argv), env=env))
     codes = [None] * n_gpus
+    failed_at = None
     while any(c is None for c in codes):
         for r, p in enumerate(procs):
             if codes[r] is None and p.poll() is not None:
                 codes[r] = p.returncode
                 if p.returncode != 0:        # let the others leave their barrier instead of waiting for a dead rank
                     open(os.path.join(folder, "failed.%d" % r), "w").close()
+                    failed_at = failed_at or time.time()
+        if failed_at is not None and time.time() - failed_at > grace_s:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            failed_at = float("inf")         # once
         time.sleep(0.02)
     return codes
 
@@ -100,12 +209,13 @@ def init_distributed():
     barriers ever go through it."""
     if os.environ.get("CHIRON_LOCAL_WORLD"):          # a child of `chiron call --gpus N`: file barrier, no torch
         rank, world = int(os.environ["CHIRON_LOCAL_RANK"]), int(os.environ["CHIRON_LOCAL_WORLD"])
+        share = os.environ.get("CHIRON_SHARE_GPU") == "1"
         try:
-            os.sched_setaffinity(0, rank_cpus(rank, world))
+            os.sched_setaffinity(0, rank_cpus(rank, world, gpu_nodes=gpu_numa_nodes(world, share), cpus_of_node=node_cpus()))
         except (AttributeError, OSError):
             pass
-        device = 0 if os.environ.get("CHIRON_SHARE_GPU") == "1" else rank
-        return LocalRanks(rank, world, os.environ["CHIRON_BARRIER_DIR"]), rank, world, device
+        device = 0 if share else rank
+        return LocalRanks(rank, world, os.environ["CHIRON_BARRIER_DIR"], parent_pid=os.environ.get("CHIRON_PARENT_PID")), rank, world, device
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return None, 0, 1, None

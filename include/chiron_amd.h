@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CHIRON_ABI_VERSION 5
+#define CHIRON_ABI_VERSION 6
 #define CHIRON_MAX_BLOCKS 8
 #define CHIRON_CLASSES 5 /* A,C,G,T,blank (rnn.py:25 class_n=5) */
 
@@ -224,7 +224,8 @@ chiron_status chiron_engine_rnn_output(chiron_engine* e, int32_t slot, float* ou
  * chiron_engine_submit, host pointers) through the network `iterations` times (2 is enough; upstream corrections move downstream
  * means slightly), measures the mean of every input channel of every f16 weight matrix -- convolutions, LSTM input and recurrent
  * kernels -- and moves that constant out of the folded BN shift / LSTM bias.  No run-time cost afterwards.  Every slot must be idle.
- * iterations = 0 restores the uncorrected shifts.  The correction depends on the calibration windows through per-channel MEANS
+ * iterations = 0 restores the uncorrected shifts (x, seq_len and batch are then ignored and may be NULL / 0).  An input that cannot
+ * be measured (more than 256 channels; more than 256 measured inputs) is CHIRON_ERR_OVERFLOW with nothing applied.  The correction depends on the calibration windows through per-channel MEANS
  * only; `chiron call --dtype fp16` calibrates on a fixed synthetic squiggle, so every rank of a sharded run holds the same engine. */
 chiron_status chiron_engine_calibrate(chiron_engine* e, const float* x, const int32_t* seq_len, int32_t batch, int32_t iterations);
 
@@ -328,6 +329,11 @@ chiron_status chiron_write_signal_text(const char* path, const float* v, int64_t
  * (BundleEntryProto.crc32c holds its masked form; tensor_bundle.cc verifies it in Saver.restore, chiron_eval.py:276).
  * Host code, used by the checkpoint reader.                                                                        */
 chiron_status chiron_crc32c(const void* data, size_t len, uint32_t* out);
+
+/* PCI address ("0000:c1:00.0", lower case as sysfs spells it) of HIP device `device_id`: what `chiron call --gpus N` needs to put
+ * rank r on the cores of the NUMA node its GPU hangs off (/sys/bus/pci/devices/<address>/numa_node; chiron_amd/shard.py).
+ * The reference has no counterpart: it is one process on one device (chiron_eval.py:255-262).  cap >= 16.            */
+chiron_status chiron_device_pci_bus_id(int32_t device_id, char* out, size_t cap);
 
 const char* chiron_last_error(void);
 int32_t chiron_abi_version(void);

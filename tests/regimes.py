@@ -38,7 +38,9 @@ def saturated_gate_weights(spec, name, seed=9):
     return w
 
 
-def trained_like_weights(spec, x_calib, seed=5, lstm_gain=3.0, gate_spread=3.0, chan_sigma=1.0, filter_mean=0.6):
+def trained_like_weights(spec, x_calib, seed=5, lstm_gain=3.0, gate_spread=3.0, chan_sigma=1.0, filter_mean=0.6, forget_mean=1.0):
+    """forget_mean: centre of the forget-gate biases (TF adds its forget_bias 1.0 on top).  1.0 = long memories (outputs change every
+    ~15 frames); -2.0 = cells that follow their input, as a basecaller's must to emit a base every 9 samples (dense_head)."""
     from oracle import nn_oracle
     w = ca.synthetic_weights(spec, seed=seed, lstm_gain=lstm_gain)
     rng = np.random.RandomState(seed + 1000)
@@ -62,7 +64,7 @@ def trained_like_weights(spec, x_calib, seed=5, lstm_gain=3.0, gate_spread=3.0, 
             b = np.empty(4 * h)
             b[0:h] = rng.normal(0.0, gate_spread, h)           # i
             b[h:2 * h] = rng.normal(0.0, 0.5, h)               # j
-            b[2 * h:3 * h] = rng.normal(1.0, gate_spread, h)   # f (+1.0 forget bias on top)
+            b[2 * h:3 * h] = rng.normal(forget_mean, gate_spread, h)   # f (+1.0 forget bias on top)
             b[3 * h:4 * h] = rng.normal(0.0, gate_spread, h)   # o
             w[k] = b.astype(np.float32)
     # population statistics = the moments the data really has at each site (float64 walk, upstream sites already calibrated)
@@ -96,3 +98,16 @@ def peaked_head(w, gain=4.0, blank_bias=2.0):
     bc[4] += blank_bias
     w["rnn_fnn_layer/bias_class"] = bc
     return w
+
+
+def dense_head(spec, w, x_calib, seq_len, bases_per_window):
+    """A trained-CTC-like head that EMITS: most frames blank, a base every few frames -- `bases_per_window` on the calibration
+    windows (a trained Chiron model decodes 16 .. 45 bases per 400-sample window: chiron/example_data/DNA/output/segments).
+    ca.fit_emitting_head on the float64 oracle's recurrent output: the class layer is FITTED, the way a trained head is.  Needs
+    cells that follow their input: trained_like_weights(forget_mean=-2)."""
+    from oracle import nn_oracle
+    sd = spec.to_dict()
+    w64 = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
+    x = np.asarray(x_calib, dtype=np.float64)
+    h = nn_oracle.rnn_forward(nn_oracle.cnn_forward(x, sd, w64), seq_len, sd, w64)          # [B, T, 2H]
+    return ca.fit_emitting_head(w, h, x, seq_len, bases_per_window, hidden=spec.hidden)

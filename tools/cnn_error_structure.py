@@ -45,68 +45,7 @@ def rms(a):
     return float(np.sqrt((np.asarray(a, dtype=np.float64) ** 2).mean()))
 
 
-def fold(w, site):
-    """engine.hip:fold_bn in float32: inv = (1/sqrt(var + eps))*scale, shift = offset - mean*inv"""
-    sc, of, mu, var = [w[site + "_bn/" + k].astype(F32) for k in ("scale", "offset", "pop_mean", "pop_var")]
-    inv = ((F32(1.0) / np.sqrt(var + F32(nn_oracle.BN_EPS))).astype(F32) * sc).astype(F32)
-    return inv, (of - (mu * inv).astype(F32)).astype(F32)
-
-
-def fma32(a, b, c):
-    """fl32(a*b + c) with one rounding: the product of two floats is exact in float64; the float64 sum is then rounded to float32
-    (double rounding differs from a true fmaf in about one case in 2^29: immaterial for error statistics)"""
-    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F32)
-
-
-def conv_chain(x, wf, shift, stride):
-    """ONE sequential fmaf chain per output over K = taps x channels, accumulator initialised with the shift (gemm.hip: the shift is
-    the C operand of a tile's first MFMA; K order = tap-major, channels ascending, as upload_gemm lays Wt out)"""
-    B, W, cin = x.shape
-    k, _, cout = wf.shape
-    out, left, right = nn_oracle.same_padding(W, k, stride)
-    xp = np.zeros((B, W + left + right, cin), dtype=F32)
-    xp[:, left:left + W] = x
-    acc = np.broadcast_to(shift.astype(F32), (B, out, cout)).copy()
-    for tap in range(k):
-        xs = xp[:, tap:tap + (out - 1) * stride + 1:stride]
-        for c in range(cin):
-            acc = fma32(xs[:, :, c:c + 1], wf[tap, c][None, None, :], acc)
-    return acc
-
-
-def block_f32(x, w, blk, order):
-    """one residual block (cnn.py:234-262) in float32, population BN, in summation order `order`"""
-    if order == "natural":
-        return nn_oracle.residual_layer(x.astype(F32), {k: v.astype(F32) for k, v in w.items()}, blk, "population")
-    n, s = blk["name"], blk.get("stride", 1)
-
-    def conv(xx, site, stride, bn, relu):
-        W = w[site + "/weights"]
-        W = W.reshape(W.shape[-3], W.shape[-2], W.shape[-1]).astype(F32)
-        if bn:
-            inv, sh = fold(w, site)
-            W = (W * inv[None, None, :]).astype(F32)
-        else:
-            sh = np.zeros(W.shape[-1], F32)
-        if order == "chain" and W.shape[1] > 1:
-            y = conv_chain(xx.astype(F32), W, sh, stride)
-        else:
-            y = (nn_oracle.conv1d_same(xx.astype(F32), W, stride) + sh).astype(F32)
-        return np.maximum(y, 0) if relu else y
-
-    b1 = conv(x, n + "/branch1/conv1", s, blk["i_bn"], False)
-    a = conv(x, n + "/branch2/conv2a", 1, True, True)
-    b = conv(a, n + "/branch2/conv2b", s, True, True)
-    c = conv(b, n + "/branch2/conv2c", 1, True, False)
-    return np.maximum((b1 + c).astype(F32), 0)
-
-
-def restatement_blocks(x, spec_d, w, order):
-    out, p = [], np.asarray(x, dtype=F32)[:, :, None]
-    for blk in spec_d["cnn"]:
-        p = block_f32(p, w, blk, order)
-        out.append(p)
-    return out
+fold, fma32, conv_chain, block_f32, restatement_blocks = pb.fold, pb.fma32, pb.conv_chain, pb.block_f32, pb.restatement_blocks
 
 
 def engine_blocks(spec, w, x, ln, L):

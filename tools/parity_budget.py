@@ -80,6 +80,80 @@ def oracle_stages(spec, w, x, sl, dtype):
     return out
 
 
+F32 = np.float32
+
+
+# ---- float32 restatements of getcnnfeature in OTHER summation orders than oracle/nn_oracle.py's.  The logits' deviation is the
+# features' rounding error amplified by the recurrent stack, and the amplification is ill-conditioned (one window of a weight set
+# can carry 1000 x: tools/cnn_error_structure.py) -- so "engine / numpy-fp32" against ONE realisation of float32 rounding is a noisy
+# statistic.  These are the other realisations an fp32 implementation of the SAME formulas may legitimately have:
+#   natural  nn_oracle in float32: BLAS, one K = C chain per tap, BN applied to the rounded sum
+#   folded   BN folded into the filters (what the engine and any inference runtime does), BLAS chains
+#   chain    folded, ONE sequential fmaf chain over the whole K starting from the shift: what an MFMA accumulator (or a plain loop) does
+def fold(w, site):
+    """engine.hip:fold_bn in float32: inv = (1/sqrt(var + eps))*scale, shift = offset - mean*inv"""
+    sc, of, mu, var = [w[site + "_bn/" + k].astype(F32) for k in ("scale", "offset", "pop_mean", "pop_var")]
+    inv = ((F32(1.0) / np.sqrt(var + F32(nn_oracle.BN_EPS))).astype(F32) * sc).astype(F32)
+    return inv, (of - (mu * inv).astype(F32)).astype(F32)
+
+
+def fma32(a, b, c):
+    """fl32(a*b + c) with one rounding: the product of two floats is exact in float64; the float64 sum is then rounded to float32
+    (double rounding differs from a true fmaf in about one case in 2^29: immaterial for error statistics)"""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F32)
+
+
+def conv_chain(x, wf, shift, stride):
+    """ONE sequential fmaf chain per output over K = taps x channels, accumulator initialised with the shift (gemm.hip: the shift is
+    the C operand of a tile's first MFMA; K order = tap-major, channels ascending, as upload_gemm lays Wt out)"""
+    B, W, cin = x.shape
+    k, _, cout = wf.shape
+    out, left, right = nn_oracle.same_padding(W, k, stride)
+    xp = np.zeros((B, W + left + right, cin), dtype=F32)
+    xp[:, left:left + W] = x
+    acc = np.broadcast_to(shift.astype(F32), (B, out, cout)).copy()
+    for tap in range(k):
+        xs = xp[:, tap:tap + (out - 1) * stride + 1:stride]
+        for c in range(cin):
+            acc = fma32(xs[:, :, c:c + 1], wf[tap, c][None, None, :], acc)
+    return acc
+
+
+def block_f32(x, w, blk, order):
+    """one residual block (cnn.py:234-262) in float32, population BN, in summation order `order`"""
+    if order == "natural":
+        return nn_oracle.residual_layer(x.astype(F32), {k: v.astype(F32) for k, v in w.items()}, blk, "population")
+    n, s = blk["name"], blk.get("stride", 1)
+
+    def conv(xx, site, stride, bn, relu):
+        W = w[site + "/weights"]
+        W = W.reshape(W.shape[-3], W.shape[-2], W.shape[-1]).astype(F32)
+        if bn:
+            inv, sh = fold(w, site)
+            W = (W * inv[None, None, :]).astype(F32)
+        else:
+            sh = np.zeros(W.shape[-1], F32)
+        if order == "chain" and W.shape[1] > 1:
+            y = conv_chain(xx.astype(F32), W, sh, stride)
+        else:
+            y = (nn_oracle.conv1d_same(xx.astype(F32), W, stride) + sh).astype(F32)
+        return np.maximum(y, 0) if relu else y
+
+    b1 = conv(x, n + "/branch1/conv1", s, blk["i_bn"], False)
+    a = conv(x, n + "/branch2/conv2a", 1, True, True)
+    b = conv(a, n + "/branch2/conv2b", s, True, True)
+    c = conv(b, n + "/branch2/conv2c", 1, True, False)
+    return np.maximum((b1 + c).astype(F32), 0)
+
+
+def restatement_blocks(x, spec_d, w, order):
+    out, p = [], np.asarray(x, dtype=F32)[:, :, None]
+    for blk in spec_d["cnn"]:
+        p = block_f32(p, w, blk, order)
+        out.append(p)
+    return out
+
+
 def local_reference(spec, w, stage, prev_impl, x, sl):
     """float64 oracle's `stage` applied to an implementation's previous-stage output"""
     sd = spec.to_dict()
@@ -129,7 +203,19 @@ def greedy_report(logits_impl, logits64, sl, err_max):
             "smallest_margin": float(m.min()), "margin_quantiles": {q: float(np.quantile(m, float(q))) for q in ("0.001", "0.01", "0.1", "0.5")}}
 
 
-def budget(topology, n_windows, peaked, seed=67, weight_seed=5):
+def fp32_order_logits(spec, w, x, sl, order):
+    """logits (and features) of a float32 pipeline whose CNN sums in `order` ("folded" / "chain"; "natural" is oracle_stages with
+    float32); the recurrent stack and the head are nn_oracle in float32 in every order"""
+    sd = spec.to_dict()
+    w32 = {k: np.asarray(v, dtype=F32) for k, v in w.items()}
+    fea = restatement_blocks(x, sd, w, order)[-1]
+    p = fea
+    for n in range(spec.rnn_layers):
+        p = nn_oracle.rnn_layer_forward(p, sl, sd, w32, n)
+    return fea, nn_oracle.fc_head(p, w32)
+
+
+def budget(topology, n_windows, peaked, seed=67, weight_seed=5, orders=()):
     spec = ca.dna_default_spec() if topology == "dna" else ca.rna_default_spec()
     L, jump = (400, 390) if topology == "dna" else (500, 490)
     x, ln = windows(jump * (n_windows - 1) + 200, L, jump, seed)
@@ -159,6 +245,12 @@ def budget(topology, n_windows, peaked, seed=67, weight_seed=5):
             prev = impl[s]
     lg = rep["stages"]["logits"]
     rep["logits_ratio_engine_over_numpy_fp32"] = {k: lg["engine_total"][k] / max(lg["numpy_fp32_total"][k], 1e-30) for k in ("max", "rms")}
+    # other float32 summation orders of the same formulas: the spread of the reference itself (see fp32_order_logits)
+    lmask = np.broadcast_to(fmask, o64["logits"].shape)
+    rep["numpy_fp32_orders"] = {"natural": {"features": stats(n32["features"], o64["features"]), "logits": lg["numpy_fp32_total"]}}
+    for o in orders:
+        fea_o, lg_o = fp32_order_logits(spec, w, x, sl, o)
+        rep["numpy_fp32_orders"][o] = {"features": stats(fea_o, o64["features"]), "logits": stats(lg_o, o64["logits"], lmask)}
     rep["greedy_engine_vs_float64"] = greedy_report(eng["logits"], o64["logits"], sl, lg["engine_total"]["max"])
     rep["greedy_numpy_fp32_vs_float64"] = greedy_report(n32["logits"], o64["logits"], sl, lg["numpy_fp32_total"]["max"])
     # the device's own decode of its own logits is the oracle's decode of those logits (bit-exact integer work)
@@ -178,11 +270,13 @@ def main():
     ap.add_argument("--peaked", action="store_true")
     ap.add_argument("--weight-seeds", default="5", help="comma separated: one budget per topology and seed (the max-norm ratio of two "
                     "amplified rounding errors is a noisy statistic; several weight sets show its spread)")
+    ap.add_argument("--orders", default="", help="comma separated float32 summation orders besides nn_oracle's: folded, chain")
     a = ap.parse_args()
     tag, n, peaked = a.tag, a.windows, a.peaked
     seeds = [int(v) for v in a.weight_seeds.split(",")]
     out = {"tag": tag, "lib": os.environ.get("CHIRON_AMD_LIB") or "product",
-           "budgets": [budget(t, n, peaked, seed=67 + 10 * k, weight_seed=ws) for t in ("dna", "rna") for k, ws in enumerate(seeds)]}
+           "budgets": [budget(t, n, peaked, seed=67 + 10 * k, weight_seed=ws, orders=tuple(v for v in a.orders.split(",") if v))
+                       for t in ("dna", "rna") for k, ws in enumerate(seeds)]}
     if len(seeds) > 1:
         out["ratio_engine_over_numpy_fp32_by_seed"] = {
             t: {m: [b["logits_ratio_engine_over_numpy_fp32"][m] for b in out["budgets"] if b["topology"] == t] for m in ("max", "rms")}
@@ -202,6 +296,8 @@ def main():
                       e["engine_at_logits"]["max"], e["engine_at_logits"]["rms"],
                       e["numpy_fp32_total"]["max"], e["numpy_fp32_total"]["rms"], e["numpy_fp32_local"]["max"], e["numpy_fp32_local"]["rms"],
                       e["numpy_fp32_at_logits"]["max"], e["numpy_fp32_at_logits"]["rms"]))
+        print("  float32 summation orders at the logits (max / rms): " + "  ".join("%s %.3g / %.3g" % (o, v["logits"]["max"], v["logits"]["rms"])
+                                                                                   for o, v in b["numpy_fp32_orders"].items()))
         g = b["greedy_engine_vs_float64"]
         print("  greedy: %d / %d windows identical, %d flipped frames (largest float64 margin %.3g, logit error %.3g)" % (
             g["identical_windows"], g["windows"], g["flipped_frames"], g["largest_margin_of_a_flipped_frame"], g["logit_error_max"]))

@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="reads per chunk (0: all at once); the disk holds one chunk at a time")
     ap.add_argument("--input", default="signal", choices=["signal", "fast5"], help="input files: .signal text or fast5 (direct path)")
     ap.add_argument("--keep", action="store_true", help="keep the chunk folders (inputs and both output trees)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp32-split"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "fp16-w2", "fp32-split"])
     ap.add_argument("--launcher", default="torchrun", choices=["torchrun", "local"],
                     help="who starts the ranks: torch.distributed.run, or `chiron call --gpus N` itself (file barrier, no torch)")
     a = ap.parse_args()
