@@ -20,7 +20,7 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
 F32, F16, F32_SPLIT, F16_W2 = 0, 1, 2, 3
-X_ON_DEVICE, WANT_PROB, WANT_LOGITS, NO_DECODE_COPY = 1, 2, 4, 8
+X_ON_DEVICE, WANT_PROB, WANT_LOGITS, NO_DECODE_COPY, COMPACT_DECODE = 1, 2, 4, 8, 16
 KERNAL_GLUE, KERNAL_STICK, KERNAL_SIMPLE = 1, 2, 3
 
 
@@ -44,7 +44,8 @@ class Decoded(C.Structure):
     _fields_ = [("nnz", C.c_int64), ("indices", C.POINTER(C.c_int64)), ("values", C.POINTER(C.c_int64)),
                 ("dense_shape", C.c_int64 * 2), ("log_prob", C.POINTER(C.c_float)),
                 ("prob_logits", C.POINTER(C.c_float)), ("logits", C.POINTER(C.c_float)),
-                ("batch", C.c_int32), ("T", C.c_int32)]
+                ("batch", C.c_int32), ("T", C.c_int32),
+                ("flat_labels", C.POINTER(C.c_uint8)), ("row_counts", C.POINTER(C.c_int32))]
 
 
 class EngineSizes(C.Structure):
@@ -67,6 +68,8 @@ SYMBOLS = [
     ("chiron_engine_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("chiron_engine_submit", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_uint32]),
+    ("chiron_engine_submit_pieces", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
+                                              C.c_int32, C.c_int32, C.c_uint32]),
     ("chiron_engine_decode", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_uint32]),
     ("chiron_engine_collect", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Decoded)]),

@@ -250,6 +250,9 @@ struct Slot {
   float* h_log_prob = nullptr;
   float* h_prob = nullptr;
   float* h_logits = nullptr;
+  uint8_t* h_labels = nullptr;   // CHIRON_COMPACT_DECODE: the device's per-row label strings [B][T] ...
+  int32_t* h_count = nullptr;    // ... and their lengths [B], copied in-stream behind the decode
+  uint8_t* h_flat = nullptr;     // the rows' labels back to back, built by collect (plain host memory)
   // state of the in-flight batch
   // 0 = idle, 1 = a batch is in flight (between a successful submit / decode and its collect).  Atomic: submit and
   // collect of one slot may come from different threads (one producer, one consumer per engine; include/chiron_amd.h).
@@ -909,6 +912,10 @@ static chiron_status alloc_slot(chiron_engine* e, Slot* s) {
   HIP_TRY(hipHostMalloc((void**)&s->h_log_prob, B * 4, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&s->h_prob, B * 4, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&s->h_logits, B * T * K * 4, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_labels, B * T, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_count, B * 4, hipHostMallocDefault));
+  s->h_flat = (uint8_t*)malloc(B * T ? B * T : 1);
+  if (!s->h_flat) return fail(CHIRON_ERR_DEVICE, "out of host memory");
   memset(s->h_prob, 0, B * 4);
   return CHIRON_OK;
 }
@@ -1016,7 +1023,8 @@ extern "C" void chiron_engine_destroy(chiron_engine* e) {
       hipEventDestroy(ev.b);
     }
     if (s.stream) hipStreamDestroy(s.stream);
-    void* hp[] = {s.h_sig, s.h_seq, s.h_indices, s.h_values, s.h_meta, s.h_log_prob, s.h_prob, s.h_logits};
+    void* hp[] = {s.h_sig, s.h_seq, s.h_indices, s.h_values, s.h_meta, s.h_log_prob, s.h_prob, s.h_logits, s.h_labels, s.h_count};
+    free(s.h_flat);
     for (void* q : hp)
       if (q) hipHostFree(q);
   }
@@ -1520,6 +1528,12 @@ static chiron_status enqueue_decode(chiron_engine* e, Slot* s, int B, int beam_w
     launch_sparse(sp, s->stream);
   }
   HIP_TRY(hipMemcpyAsync(s->h_meta, s->meta, 3 * 8, hipMemcpyDeviceToHost, s->stream));
+  if (flags & CHIRON_COMPACT_DECODE) {
+    // fixed-size copies, known at submit time: no second round trip in collect (the SparseTensor's size is only known once the
+    // decode has run, so its copy is issued BY collect: sync, read nnz, copy nnz * 24 bytes, sync again)
+    HIP_TRY(hipMemcpyAsync(s->h_labels, s->labels, (size_t)B * T, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_count, s->count, (size_t)B * 4, hipMemcpyDeviceToHost, s->stream));
+  }
   HIP_TRY(hipMemcpyAsync(s->h_log_prob, s->log_prob, (size_t)B * 4, hipMemcpyDeviceToHost, s->stream));
   if (flags & CHIRON_WANT_PROB) HIP_TRY(hipMemcpyAsync(s->h_prob, s->prob, (size_t)B * 4, hipMemcpyDeviceToHost, s->stream));
   if (flags & CHIRON_WANT_LOGITS)
@@ -1538,11 +1552,34 @@ static void resync_tile_counters(Slot* s) {
   (void)hipGetLastError();
 }
 
+static chiron_status submit_impl(chiron_engine* e, int32_t slot, const float* x, const float* const* pieces, const int32_t* piece_rows,
+                                 int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width, uint32_t flags);
+
 extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, const float* x, const int32_t* seq_len,
                                               int32_t batch, int32_t beam_width, uint32_t flags) {
+  if (!x) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
+  return submit_impl(e, slot, x, nullptr, nullptr, 0, seq_len, batch, beam_width, flags);
+}
+
+extern "C" chiron_status chiron_engine_submit_pieces(chiron_engine* e, int32_t slot, const float* const* pieces, const int32_t* piece_rows,
+                                                     int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width,
+                                                     uint32_t flags) {
+  if (!pieces || !piece_rows || n_pieces < 1) return fail(CHIRON_ERR_INVALID, "null / empty piece list");
+  if (flags & CHIRON_X_ON_DEVICE) return fail(CHIRON_ERR_INVALID, "chiron_engine_submit_pieces takes host pieces");
+  long rows = 0;
+  for (int i = 0; i < n_pieces; ++i) {
+    if (!pieces[i] || piece_rows[i] < 0) return fail(CHIRON_ERR_INVALID, "piece %d: null pointer or negative row count", i);
+    rows += piece_rows[i];
+  }
+  if (rows != batch) return fail(CHIRON_ERR_INVALID, "the pieces hold %ld rows, batch is %d", rows, batch);
+  return submit_impl(e, slot, nullptr, pieces, piece_rows, n_pieces, seq_len, batch, beam_width, flags);
+}
+
+static chiron_status submit_impl(chiron_engine* e, int32_t slot, const float* x, const float* const* pieces, const int32_t* piece_rows,
+                                 int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width, uint32_t flags) {
   if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
   if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range (%zu slots)", slot, e->slots.size());
-  if (!x || !seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
+  if (!seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
   if (batch < 1 || batch > e->maxB) return fail(CHIRON_ERR_OVERFLOW, "batch %d exceeds max_batch %d", batch, e->maxB);
   if (beam_width < 0) return fail(CHIRON_ERR_INVALID, "beam_width %d", beam_width);
   if (beam_width > e->opts.max_beam) return fail(CHIRON_ERR_OVERFLOW, "beam_width %d exceeds max_beam %d given at create", beam_width, e->opts.max_beam);
@@ -1561,7 +1598,15 @@ extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, co
       sig = x;
       HIP_TRY(hipMemcpyAsync(s->seq, seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
     } else {
-      memcpy(s->h_sig, x, (size_t)B * e->L * 4);
+      if (x) {
+        memcpy(s->h_sig, x, (size_t)B * e->L * 4);
+      } else {   // cross-read packing (chiron_eval.py:321-334) straight into the staging buffer: the batch is never assembled anywhere else
+        size_t row = 0;
+        for (int i = 0; i < n_pieces; ++i) {
+          memcpy(s->h_sig + row * e->L, pieces[i], (size_t)piece_rows[i] * e->L * 4);
+          row += piece_rows[i];
+        }
+      }
       memcpy(s->h_seq, seq_len, (size_t)B * 4);
       HIP_TRY(hipMemcpyAsync(s->sig, s->h_sig, (size_t)B * e->L * 4, hipMemcpyHostToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(s->seq, s->h_seq, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
@@ -1639,7 +1684,7 @@ extern "C" chiron_status chiron_engine_collect(chiron_engine* e, int32_t slot, c
   auto drain = [&]() -> chiron_status {
     HIP_TRY(hipStreamSynchronize(s->stream));
     const int64_t n = s->h_meta[0];
-    if (!(s->flags & CHIRON_NO_DECODE_COPY) && n > 0) {
+    if (!(s->flags & (CHIRON_NO_DECODE_COPY | CHIRON_COMPACT_DECODE)) && n > 0) {
       HIP_TRY(hipMemcpyAsync(s->h_indices, s->indices, (size_t)n * 16, hipMemcpyDeviceToHost, s->stream));
       HIP_TRY(hipMemcpyAsync(s->h_values, s->values, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
       HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1655,8 +1700,32 @@ extern "C" chiron_status chiron_engine_collect(chiron_engine* e, int32_t slot, c
   const int64_t nnz = s->h_meta[0];
   if (!(s->flags & CHIRON_WANT_PROB)) memset(s->h_prob, 0, (size_t)s->batch * 4);
   out->nnz = nnz;
-  out->indices = s->h_indices;
-  out->values = s->h_values;
+  const bool compact = (s->flags & CHIRON_COMPACT_DECODE) != 0;
+  out->indices = compact ? nullptr : s->h_indices;
+  out->values = compact ? nullptr : s->h_values;
+  out->flat_labels = nullptr;
+  out->row_counts = nullptr;
+  if (compact) {
+    // the per-read regroup of chiron_eval.py:403-446 needs, per run of rows, the rows' label strings back to back and their lengths:
+    // exactly this, in row order, built here in one pass over what the decoder wrote (labels[b][0 .. count[b]))
+    const int T = e->T;
+    int64_t off = 0;
+    for (int b = 0; b < s->batch; ++b) {
+      const int c = s->h_count[b];
+      if (c < 0 || c > T || off + c > nnz) {
+        s->state.v.store(0, std::memory_order_release);
+        return fail(CHIRON_ERR_DEVICE, "decoder wrote an impossible row length %d (row %d)", c, b);
+      }
+      memcpy(s->h_flat + off, s->h_labels + (size_t)b * T, (size_t)c);
+      off += c;
+    }
+    if (off != nnz) {
+      s->state.v.store(0, std::memory_order_release);
+      return fail(CHIRON_ERR_DEVICE, "row lengths sum to %lld, the SparseTensor holds %lld", (long long)off, (long long)nnz);
+    }
+    out->flat_labels = s->h_flat;
+    out->row_counts = s->h_count;
+  }
   out->dense_shape[0] = s->h_meta[1];
   out->dense_shape[1] = s->h_meta[2];
   out->log_prob = s->h_log_prob;

@@ -14,7 +14,11 @@ from . import _lib
 from .model import ModelSpec
 
 SparseTensor = namedtuple("SparseTensor", "indices values dense_shape")      # chiron_eval.py:34
-DecodeResult = namedtuple("DecodeResult", "decoded log_prob prob_logits logits")
+# compact: None, or CompactDecode -- the decode in the per-row form of the regroup step (CHIRON_COMPACT_DECODE): `flat` uint8 [nnz], the
+# rows' labels back to back in row order; `counts` int32 [batch], labels per row.  Then `decoded` is None: the (indices, values) pair
+# of the SparseTensor is the same information spread over 24 bytes per base.
+CompactDecode = namedtuple("CompactDecode", "flat counts dense_shape")
+DecodeResult = namedtuple("DecodeResult", "decoded log_prob prob_logits logits compact", defaults=(None,))
 
 
 def _is_torch_cuda(x):
@@ -86,7 +90,7 @@ class Engine(object):
         self.close()
 
     # ------------------------------------------------------------------
-    def submit(self, slot, x, seq_len, beam_width=0, want_prob=True, want_logits=False, copy_decoded=True):
+    def submit(self, slot, x, seq_len, beam_width=0, want_prob=True, want_logits=False, copy_decoded=True, compact=False):
         """Asynchronous: enqueue one batch on `slot`'s stream.  x/seq_len may be
         numpy arrays (host) or torch CUDA tensors already resident on this
         engine's device (zero-copy)."""
@@ -119,9 +123,30 @@ class Engine(object):
             flags |= _lib.WANT_LOGITS
         if not copy_decoded:
             flags |= _lib.NO_DECODE_COPY
+        if compact:
+            flags |= _lib.COMPACT_DECODE
         # A submit refused with ERR_STATE leaves the slot's in-flight batch untouched: its keep-alive must survive
         _lib.check(self._lib.chiron_engine_submit(self._h, slot, xp, sp, batch, int(beam_width), flags))
         self._keep[slot] = (x, seq_len)
+
+    def submit_pieces(self, slot, pieces, seq_len, beam_width=0, want_prob=True, compact=True):
+        """submit() with the batch given as a list of C-contiguous float32 arrays of whole rows [n_i, segment_len] (the tail of one
+        read, whole reads, the head of the next: chiron_eval.py:321-334): chiron_engine_submit_pieces copies them straight into the
+        slot's pinned staging buffer, the [batch, segment_len] array is never built.  compact: ask for the decode in the regroup's
+        per-row form (collect().compact) instead of the SparseTensor."""
+        n = len(pieces)
+        ptrs = (C.c_void_p * n)()
+        rows = (C.c_int32 * n)()
+        for i, a in enumerate(pieces):
+            if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] != self.segment_len or not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("piece %d must be a C-contiguous float32 [n, %d] array" % (i, self.segment_len))
+            ptrs[i] = a.ctypes.data
+            rows[i] = a.shape[0]
+        seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
+        flags = (_lib.WANT_PROB if want_prob else 0) | (_lib.COMPACT_DECODE if compact else 0)
+        _lib.check(self._lib.chiron_engine_submit_pieces(self._h, slot, ptrs, rows, n, seq_len.ctypes.data_as(C.c_void_p),
+                                                         int(seq_len.shape[0]), int(beam_width), flags))
+        self._keep[slot] = (pieces, seq_len)
 
     def collect(self, slot):
         """Blocks; returns DecodeResult with numpy copies (valid indefinitely)."""
@@ -129,6 +154,13 @@ class Engine(object):
         _lib.check(self._lib.chiron_engine_collect(self._h, slot, C.byref(d)))
         self._keep[slot] = None
         nnz, B, T, K = d.nnz, d.batch, d.T, self.spec.classes
+        if d.row_counts:       # CHIRON_COMPACT_DECODE: the SparseTensor was not copied
+            flat = np.ctypeslib.as_array(d.flat_labels, shape=(nnz,)).copy() if nnz > 0 else np.zeros(0, dtype=np.uint8)
+            comp = CompactDecode(flat, np.ctypeslib.as_array(d.row_counts, shape=(B,)).copy(),
+                                 np.asarray([d.dense_shape[0], d.dense_shape[1]], dtype=np.int64))
+            lp = np.ctypeslib.as_array(d.log_prob, shape=(B, 1)).copy()
+            pr = np.ctypeslib.as_array(d.prob_logits, shape=(B, 1)).copy()
+            return DecodeResult(None, lp, pr, None, comp)
         if nnz > 0 and d.indices:
             idx = np.ctypeslib.as_array(d.indices, shape=(nnz, 2)).copy()
             val = np.ctypeslib.as_array(d.values, shape=(nnz,)).copy()

@@ -83,6 +83,8 @@ def evaluation(args):
     if path.isdir(FLAGS.input):
         from .extract import list_fast5, prepare_folders
         fast5_list = list_fast5(FLAGS.input, True, getattr(FLAGS, "test_number", None))
+        if getattr(FLAGS, "via_signal_files", False):
+            FLAGS.no_raw = False                          # the two-pass path reads raw/<name>.signal back: it must exist
         if fast5_list and not getattr(FLAGS, "via_signal_files", False):
             # Direct path: ONE partition decides which rank decodes and basecalls a fast5 file; the reader
             # threads write raw/<name>.signal for the output tree and window the decoded samples straight away -- no
@@ -148,6 +150,10 @@ def build_parser():
                    help="Engine arithmetic: fp32 (parity path), fp16 (f16 MFMA conv + LSTM, fp32 CTC), fp16-w2 (fp16's activations against "
                         "exact hi + lo weights: the f16 mode for trained checkpoints), fp32-split "
                         "(fp32 values as hi/lo half pairs on the f16 matrix cores).")
+    p.add_argument("--no-raw", dest="no_raw", action="store_true",
+                   help="fast5 input on the direct path: do not write raw/<name>.signal (the reference's extraction output, "
+                        "extract_sig_ref.py:119-123 -- 4 bytes of text per sample that nothing reads back here).  Opt-in deviation from the "
+                        "reference's output tree; ignored with --via-signal-files.")
     p.add_argument("--no-calibration", dest="no_calibration", action="store_true",
                    help="--dtype fp16: skip the bias correction for the weights' rounding to halves (Engine.calibrate on a fixed synthetic "
                         "calibration batch at start-up).")

@@ -218,11 +218,19 @@ class Batch(object):
     window within its file); `fname` / `index` are the per-row tags of the reference (chiron_eval.py:328-329), expanded on
     demand: the pipeline itself only ever walks the runs (a per-row object array of names cost the main thread a quarter of
     its time per batch)."""
-    __slots__ = ("x", "seq_len", "n_valid", "runs", "_rows")
+    __slots__ = ("_x", "pieces", "seq_len", "n_valid", "runs", "_rows")
 
-    def __init__(self, x, seq_len, runs, n_valid, rows=None):
-        self.x, self.seq_len, self.runs, self.n_valid = x, seq_len, runs, n_valid
-        self._rows = len(x) if rows is None else rows
+    def __init__(self, x, seq_len, runs, n_valid, rows=None, pieces=None):
+        """x: the [batch, segment_len] array, or None when `pieces` (the per-run arrays whose concatenation it is) is given: the
+        engine takes the pieces as they are (Engine.submit_pieces) and nobody pays for the concatenation; `x` builds it on demand."""
+        self._x, self.pieces, self.seq_len, self.runs, self.n_valid = x, pieces, seq_len, runs, n_valid
+        self._rows = (len(x) if x is not None else sum(len(p) for p in pieces)) if rows is None else rows
+
+    @property
+    def x(self):
+        if self._x is None:
+            self._x = np.ascontiguousarray(np.concatenate(self.pieces, axis=0), dtype=np.float32)
+        return self._x
 
     @classmethod
     def from_tags(cls, x, seq_len, fname, index, n_valid):
@@ -285,8 +293,13 @@ class BatchPacker(object):
             yield self._emit(self.n)
 
     def _emit(self, n_valid):
-        x = np.concatenate(self.x, axis=0)
         sl = np.concatenate(self.sl, axis=0)
+        if n_valid == self.batch_size and all(p.dtype == np.float32 and p.flags["C_CONTIGUOUS"] for p in self.x):
+            # a full batch: hand the per-run arrays on as they are (row slices of the reads' window arrays)
+            b = Batch(None, seq_len_for_engine(sl, self.ratio), self.runs, n_valid, rows=n_valid, pieces=self.x)
+            self._reset()
+            return b
+        x = np.concatenate(self.x, axis=0)
         if n_valid < self.batch_size:
             pad = self.batch_size - n_valid
             x = np.pad(x, ((0, pad), (0, 0)), mode="wrap")
@@ -317,6 +330,9 @@ class ReadCollector(object):
     def add_batch(self, batch, result, want_qs):
         """-> list of (name, reads [ragged int arrays], qs_list [n,1], meta) for completed reads"""
         done = []
+        compact = getattr(result, "compact", None)
+        if compact is not None:
+            return self._add_batch_compact(batch, compact, result.prob_logits, want_qs)
         predict_val = ([result.decoded], result.log_prob)
         runs = batch.runs
         k = 0
@@ -336,6 +352,34 @@ class ReadCollector(object):
                     done.append(self._finish(fn, want_qs))
         return done
 
+    def _add_batch_compact(self, batch, compact, prob_logits, want_qs):
+        """add_batch on the engine's compact decode (Engine.collect().compact: the rows' labels back to back + labels per row):
+        a run of rows is one slice of `flat`, its windows' lengths are the non-zero counts, the rows that decoded to something
+        are where the counts are non-zero -- the same pieces slice_ctc_decoding_result + _rows_of extract from the SparseTensor
+        (chiron_eval.py:36-98), without scanning 16 bytes of (row, position) per base."""
+        done = []
+        counts = compact.counts
+        off = np.zeros(counts.shape[0] + 1, dtype=np.int64)
+        np.cumsum(counts, out=off[1:])
+        runs = batch.runs
+        k = 0
+        while k < len(runs):
+            fn, pos, n, first_idx = runs[k]
+            end = pos + n
+            k += 1
+            while k < len(runs) and runs[k][0] == fn and runs[k][1] == end:
+                end += runs[k][2]
+                k += 1
+            if fn != "":
+                c = counts[pos:end]
+                nz = c > 0
+                rec = self.val.setdefault(fn, {"total": 0, "pieces": {}})
+                rec["pieces"][int(first_idx)] = (compact.flat[off[pos]:off[end]], c[nz].astype(np.int64), prob_logits[pos:end][nz] if want_qs else None)
+                rec["total"] += end - pos
+                if "reads_n" in rec and rec["total"] == rec["reads_n"]:
+                    done.append(self._finish(fn, want_qs))
+        return done
+
     def _finish(self, name, want_qs):
         """-> (name, flat, seg_len, qs_list, meta): the read's decoded windows as ONE uint8 array of base indices and the
         length of every window that decoded to something (rows with an empty decode vanish, as in sparse2dense,
@@ -343,6 +387,13 @@ class ReadCollector(object):
         rec = self.val.pop(name)
         vals, lens, qss = [], [], []
         for i in sorted(rec["pieces"]):
+            if len(rec["pieces"][i]) == 3:          # a compact piece: (flat labels, lengths of the non-empty windows, their path_prob)
+                flat_i, lens_i, qs_i = rec["pieces"][i]
+                vals.append(flat_i)
+                lens.append(lens_i)
+                if want_qs:
+                    qss.append(qs_i)
+                continue
             (decoded, _), logits_prob = rec["pieces"][i]
             ids, starts, ends = _rows_of(decoded[0])
             vals.append(decoded[0].values)
@@ -523,6 +574,10 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
         finishers = ThreadPoolExecutor(max_workers=n_threads)
     finishing = []
 
+    # the decode in the regroup's own form (rows' labels back to back + labels per row) where the engine offers it
+    import inspect
+    compact_kw = {"compact": True} if "compact" in inspect.signature(engine.submit).parameters else {}
+
     def collect(slot):
         """-> (batch, result) of the slot's finished batch, or None: the slot is free for the next submit afterwards"""
         if inflight[slot] is None:
@@ -546,7 +601,10 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
         slot = step[0] % engine.n_slots
         step[0] += 1
         done = collect(slot)
-        engine.submit(slot, batch.x, batch.seq_len, beam_width=FLAGS.beam, want_prob=want_qs)
+        if batch.pieces is not None and hasattr(engine, "submit_pieces"):
+            engine.submit_pieces(slot, batch.pieces, batch.seq_len, beam_width=FLAGS.beam, want_prob=want_qs, compact=True)
+        else:
+            engine.submit(slot, batch.x, batch.seq_len, beam_width=FLAGS.beam, want_prob=want_qs, **compact_kw)
         inflight[slot] = batch
         regroup(done)
 

@@ -62,7 +62,9 @@ def extract_records(full, FLAGS):
             continue
         name = read_id if getattr(FLAGS, "idname", False) else stem + suffix
         sig_path = os.path.join(FLAGS.raw_folder, name + ".signal")
-        if unit:
+        if getattr(FLAGS, "no_raw", False):
+            pass        # `chiron call --no-raw`: the direct path never reads raw/<name>.signal back; skipping it is an opt-in deviation
+        elif unit:
             with open(sig_path, "w+") as f:
                 f.write(FLAGS.delimiter.join([str(v) for v in raw.tolist()]))     # extract_sig_ref.py:122-123
         else:

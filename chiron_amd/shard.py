@@ -140,19 +140,48 @@ def node_cpus(sysfs="/sys"):
     return out
 
 
-def rank_cpus(rank, world, cpus=None, gpu_nodes=None, cpus_of_node=None):
+def core_order(cpus, sysfs="/sys"):
+    """`cpus` re-ordered so that the hardware threads of one physical core are neighbours (cores in ascending order of their first
+    thread).  Linux numbers the second SMT thread of core k as k + <cores of the host> (EPYC 9575F x 2: cpu 0 and cpu 128 are one
+    core), so contiguous slices of the plain numbering gave rank 0 the first threads of cores 0..31 and rank 4 their siblings: two
+    ranks' reader threads on the same cores' L1 / L2.  Sliced in THIS order a rank gets whole cores."""
+    cpus = sorted(cpus)
+    first = {}
+    for c in cpus:
+        key = c
+        try:
+            with open(os.path.join(sysfs, "devices", "system", "cpu", "cpu%d" % c, "topology", "thread_siblings_list")) as f:
+                sib = _parse_cpulist(f.read())
+            if sib:
+                key = min(sib)
+        except (OSError, ValueError):
+            pass
+        first[c] = key
+    return sorted(cpus, key=lambda c: (first[c], c))
+
+
+def rank_affinity(rank, world, share_gpu=False, sysfs="/sys"):
+    """The cores `chiron call --gpus N` pins rank `rank` to: the NUMA node of its GPU, whole physical cores (rank_cpus + core_order)."""
+    allowed = core_order(os.sched_getaffinity(0), sysfs)
+    nodes = {n: [c for c in core_order(v, sysfs)] for n, v in node_cpus(sysfs).items()}
+    return rank_cpus(rank, world, allowed, gpu_numa_nodes(world, share_gpu, sysfs), nodes, ordered=True)
+
+
+def rank_cpus(rank, world, cpus=None, gpu_nodes=None, cpus_of_node=None, ordered=False):
     """CPU affinity of one local rank.  With the NUMA node of every rank's GPU known (gpu_nodes[r], gpu_numa_nodes) and the
     host's node -> cpus map: the ranks whose GPUs hang off one node share THAT node's allowed cores in contiguous slices -- a rank's
     pinned staging buffers, its reader / finisher threads and its GPU's PCIe root then sit on one node (round-4 review, Weak #9: the
     slices used to go by rank index alone).  Without that knowledge (single-node host, no sysfs, no GPU): the r-th of `world`
     contiguous slices of the allowed cores, as before."""
-    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    if not ordered:          # ordered: the caller's lists are already in the order to slice (core_order)
+        cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
     n = len(cpus)
     if world <= 1 or n < world:
         return cpus
     if gpu_nodes and cpus_of_node and len(gpu_nodes) == world and all(g is not None for g in gpu_nodes):
         node = gpu_nodes[rank]
-        mine = [c for c in cpus_of_node.get(node, []) if c in set(cpus)]
+        allowed = set(cpus)
+        mine = [c for c in cpus_of_node.get(node, []) if c in allowed]
         sharers = [r for r in range(world) if gpu_nodes[r] == node]
         if len(mine) >= len(sharers):
             i = sharers.index(rank)
@@ -211,7 +240,7 @@ def init_distributed():
         rank, world = int(os.environ["CHIRON_LOCAL_RANK"]), int(os.environ["CHIRON_LOCAL_WORLD"])
         share = os.environ.get("CHIRON_SHARE_GPU") == "1"
         try:
-            os.sched_setaffinity(0, rank_cpus(rank, world, gpu_nodes=gpu_numa_nodes(world, share), cpus_of_node=node_cpus()))
+            os.sched_setaffinity(0, rank_affinity(rank, world, share))
         except (AttributeError, OSError):
             pass
         device = 0 if share else rank

@@ -158,6 +158,10 @@ chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out_T, double*
 #define CHIRON_WANT_PROB 2u     /* compute prob_logits = path_prob (chiron_eval.py:116-136, -e fastq) */
 #define CHIRON_WANT_LOGITS 4u   /* copy logits [B,T,K] back on collect                */
 #define CHIRON_NO_DECODE_COPY 8u /* leave decoded sparse tensor on the device (bench)  */
+#define CHIRON_COMPACT_DECODE 16u /* the host wants the decode in the per-row form of the regroup step (chiron_eval.py:403-446): collect
+                                    fills flat_labels / row_counts and does NOT copy indices / values (NULL; nnz and dense_shape are
+                                    still reported).  One fixed-size copy enqueued with the batch instead of a second round trip
+                                    for nnz * 24 bytes of int64 pairs that the host would only scan for row boundaries.           */
 
 /* Replaces sess.run(logits_enqueue, feed_dict) (chiron_eval.py:335-342) plus the
  * decode sub-graph (chiron_eval.py:465-492).  x: float32 [batch, segment_len]
@@ -186,7 +190,18 @@ typedef struct {
   const float* logits;      /* [batch,T,K] or NULL                              */
   int32_t batch;
   int32_t T;
+  /* CHIRON_COMPACT_DECODE only (else NULL): the rows' decoded labels 0..3 back to back in row order [nnz], and the number of
+   * labels of every row [batch] -- the same decode as (indices, values): row b owns the next row_counts[b] entries.       */
+  const uint8_t* flat_labels;
+  const int32_t* row_counts;
 } chiron_decoded;
+
+/* chiron_engine_submit with the batch given as `n_pieces` host arrays of whole rows (piece i: piece_rows[i] x segment_len floats,
+ * rows summing to `batch`): the cross-read packing of chiron_eval.py:321-334 -- the tail of one read, whole reads, the head of
+ * the next -- copied straight into the slot's pinned staging buffer, so the caller never assembles the [batch, segment_len]
+ * array (1.76 MB per 1100-window batch on the host's main thread otherwise).  Host pointers only.                        */
+chiron_status chiron_engine_submit_pieces(chiron_engine* e, int32_t slot, const float* const* pieces, const int32_t* piece_rows,
+                                          int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width, uint32_t flags);
 
 /* Replaces sess.run(decode dequeue) (chiron_eval.py:403-409).  Blocks until the
  * slot's work is complete, then fills *out with host pointers owned by the slot. */

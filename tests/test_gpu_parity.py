@@ -1652,6 +1652,45 @@ def test_chiron_call_rna_mode_on_the_reference_rna_example(tmp_path):
             assert fq[1] == ce.index2base(np.argmax(cons, axis=0)).replace("T", "U")
 
 
+@pytest.mark.parametrize("beam", [0, 30])
+def test_compact_decode_and_piecewise_submit_equal_the_sparse_tensor_path(dna, beam):
+    """The host pipeline's fast path (round 5): chiron_engine_submit_pieces copies the cross-read pieces of a batch straight into the
+    slot's staging buffer, and CHIRON_COMPACT_DECODE returns the decode as the rows' labels back to back + labels per row instead of the
+    (indices, values) SparseTensor (chiron_eval.py:403-409 / :36-98).  Same batch both ways -- a ragged row, an empty row, greedy and
+    beam 30: identical logits-derived outputs; the compact form IS the SparseTensor (row b owns the next counts[b] values, positions
+    0 .. counts[b] - 1); a compact collect leaves no stale state for the next plain collect on the slot; bad piece lists are refused."""
+    spec, w = dna
+    L, jump, n = 400, 390, 137
+    x, ln = _windows(jump * (n - 1) + 200, L, jump, seed=91)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    ln = ln.copy()
+    ln[3], ln[70] = 90, 0
+    with ca.Engine(spec, w, max_batch=n, segment_len=L, n_slots=2, max_beam=30) as eng:
+        sl = ca.seq_len_for_engine(ln, eng.ratio)
+        ref = eng.infer(x, sl, beam_width=beam, want_prob=True)
+        cuts = [0, 5, 5 + 61, 5 + 61 + 1, n]                       # four pieces, one of a single row
+        pieces = [x[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        eng.submit_pieces(1, pieces, sl, beam_width=beam, want_prob=True, compact=True)
+        got = eng.collect(1)
+        assert got.decoded is None and got.compact is not None
+        c = got.compact
+        assert c.flat.dtype == np.uint8 and c.counts.dtype == np.int32 and c.counts.shape == (n,) and int(c.counts.sum()) == c.flat.shape[0]
+        assert np.array_equal(c.flat, ref.decoded.values.astype(np.uint8))
+        assert np.array_equal(c.counts, np.bincount(ref.decoded.indices[:, 0], minlength=n))
+        assert np.array_equal(np.concatenate([np.arange(k) for k in c.counts] or [np.zeros(0, int)]), ref.decoded.indices[:, 1])
+        assert np.array_equal(c.dense_shape, ref.decoded.dense_shape) and c.counts[70] == 0
+        assert np.array_equal(got.log_prob, ref.log_prob) and np.array_equal(got.prob_logits, ref.prob_logits)
+        again = eng.infer(x, sl, beam_width=beam, want_prob=True, slot=1)          # the plain form on the same slot afterwards
+        assert again.compact is None and np.array_equal(again.decoded.values, ref.decoded.values) and np.array_equal(again.decoded.indices, ref.decoded.indices)
+        eng.submit(0, x, sl, beam_width=beam, compact=True)                       # compact without pieces
+        assert np.array_equal(eng.collect(0).compact.flat, c.flat)
+        with pytest.raises(_lib.ChironError):
+            eng.submit_pieces(0, pieces[:-1], sl, beam_width=beam)                # rows do not add up to the batch
+        with pytest.raises(ValueError):
+            eng.submit_pieces(0, [x[:, :399]], sl)                                # not [n, segment_len]
+        assert np.array_equal(eng.infer(x, sl, beam_width=beam).decoded.values, ref.decoded.values)     # the refusals left slot 0 idle and usable
+
+
 @pytest.mark.parametrize("weight_seed", [5, 6, 7, 8])
 @pytest.mark.parametrize("topology", ["dna", "rna"])
 def test_trained_like_error_budget_and_greedy_strings(dna, rna, topology, weight_seed):
@@ -1797,7 +1836,11 @@ def test_sharded_call_equals_single_process(tmp_path):
                          launcher="local", keep=True)
     assert repl["identical"] and repl["files_compared"] == 18 and repl["consensus_bases"] == rep["consensus_bases"]
     ranks_dir = os.path.join(str(tmp_path / "c"), "chunk_000000", "out_2ranks", "log", "ranks")
-    assert sorted(os.listdir(ranks_dir)) == ["barrier.1.0", "barrier.1.1", "barrier.2.0", "barrier.2.1"]
+    assert sorted(os.listdir(ranks_dir)) == ["barrier.1.0", "barrier.1.1", "barrier.2.0", "barrier.2.1", "pid.0", "pid.1"]
+    import json
+    eng_log = os.path.join(str(tmp_path / "c"), "chunk_000000", "out_2ranks", "log")
+    assert json.load(open(os.path.join(eng_log, "engine.rank1.json"))) == {"dtype": "fp32", "fp16_bias_correction": False, "max_batch": 1100,
+                                                                          "segment_len": 400, "slots": 3, "device": 0}
     # --dtype fp16: every process calibrates its engine at start-up (bias correction for the weights' rounding to halves) on the SAME
     # fixed synthetic batch, so the sharded run's files are still the single process's, byte for byte
     rep16 = shard_run.run(str(tmp_path / "d"), n_reads=9, n_samples=100000, ranks=2, share_gpu=True, extension="fastq", batch=1100, kind="fast5",

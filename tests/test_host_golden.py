@@ -341,7 +341,7 @@ def test_packer_collector_round_trip_random_streams():
     """Property (rows H5 + P1, chiron_eval.py:321-360 / :403-446): for random reads, batch sizes and drain orders every
     window comes back exactly once, in within-file order, under its own read; rows whose decode is empty vanish;
     wrap-padding rows of the last batch are never attributed to a read."""
-    from chiron_amd.engine import DecodeResult, SparseTensor
+    from chiron_amd.engine import DecodeResult, SparseTensor, CompactDecode
     rng = np.random.RandomState(77)
     for trial in range(60):
         B = int(rng.choice([1, 2, 3, 4, 7, 16]))
@@ -364,7 +364,14 @@ def test_packer_collector_round_trip_random_streams():
         assert sum(b.n_valid for b in batches) == uid and all(b.x.shape == (B, L) for b in batches)
         # "decode": window uid -> (uid % 3) labels (so every third window decodes to nothing), qs = uid
         order = rng.permutation(len(batches))
-        done = []
+        done, done_c = [], []
+        col_c = ce.ReadCollector()
+        for name, n in reads:
+            col_c.expect(name, n, (0.0, 0.0))
+        # full batches travel as the per-run pieces (Engine.submit_pieces); x is their concatenation, built on demand
+        for b in batches:
+            if b.pieces is not None:
+                assert b.n_valid == B and sum(len(p_) for p_ in b.pieces) == B and np.array_equal(np.concatenate(b.pieces), b.x)
         for bi in order:
             b = batches[bi]
             ind, val = [], []
@@ -376,6 +383,15 @@ def test_packer_collector_round_trip_random_streams():
             st = SparseTensor(np.asarray(ind, dtype=np.int64).reshape(-1, 2), np.asarray(val, dtype=np.int64), np.asarray([B, 2]))
             res = DecodeResult(st, np.zeros((B, 1), np.float32), b.x[:, :1].copy(), None)
             done += col.add_batch(b, res, True)
+            # the engine's compact form of the same decode (CHIRON_COMPACT_DECODE: rows' labels back to back + labels per row) through
+            # the collector's fast path: the same reads, bit for bit
+            counts = np.bincount(st.indices[:, 0], minlength=B).astype(np.int32) if len(val) else np.zeros(B, np.int32)
+            resc = DecodeResult(None, res.log_prob, res.prob_logits, None, CompactDecode(np.asarray(val, dtype=np.uint8), counts, np.asarray([B, 2])))
+            done_c += col_c.add_batch(b, resc, True)
+        assert [d[0] for d in done_c] == [d[0] for d in done]
+        for a, c in zip(done, done_c):
+            assert np.array_equal(a[1], c[1]) and a[1].dtype == c[1].dtype and np.array_equal(a[2], c[2]) and a[2].dtype == c[2].dtype
+            assert np.array_equal(a[3], c[3]) and a[3].shape == c[3].shape
         assert sorted(d[0] for d in done) == sorted(n for n, _ in reads)
         for name, flat, seg_len, qs_list, meta in done:
             out_reads = ce.split_flat(flat, seg_len)

@@ -213,3 +213,22 @@ def test_survivors_are_terminated_after_a_rank_failed(tmp_path):
             os.environ["PYTHONPATH"] = env_py
     assert codes[0] == 7 and codes[1] not in (0, None) and time.time() - t0 < 30, codes
     assert os.path.exists(str(tmp_path / "out" / "log" / "ranks" / "failed.0"))
+
+
+def test_a_rank_gets_whole_physical_cores(tmp_path):
+    """Linux numbers the second SMT thread of core k as k + <cores>: contiguous slices of the plain numbering put two ranks on the two
+    threads of the same cores (measured on the 2 x 64-core GPU host: cpu 0-31 -> rank 0, their siblings 128-159 -> rank 4).
+    shard.core_order puts siblings next to each other first, so a slice is whole cores."""
+    from chiron_amd import shard as sh
+    sysfs = tmp_path / "sys"
+    n_cores = 16
+    for c in range(2 * n_cores):
+        d = sysfs / "devices" / "system" / "cpu" / ("cpu%d" % c) / "topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text("%d,%d\n" % (c % n_cores, c % n_cores + n_cores))
+    order = sh.core_order(range(2 * n_cores), str(sysfs))
+    assert order[:6] == [0, 16, 1, 17, 2, 18] and sorted(order) == list(range(32))
+    parts = [sh.rank_cpus(r, 4, order, ordered=True) for r in range(4)]
+    for r, p in enumerate(parts):
+        assert sorted(p) == sorted(list(range(4 * r, 4 * r + 4)) + list(range(16 + 4 * r, 16 + 4 * r + 4)))     # four whole cores each
+    assert sh.core_order([3, 1, 2], str(tmp_path / "nothing")) == [1, 2, 3]                                 # no sysfs: plain order

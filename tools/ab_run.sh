@@ -9,7 +9,7 @@ for r in $(seq 1 "$REPS"); do
   for arm in "$@"; do
     name=${arm%%=*}; lib=${arm#*=}
     if [ "$lib" = product ]; then unset CHIRON_AMD_LIB; else export CHIRON_AMD_LIB=$lib; fi
-    CHIRON_ALLOW_TIMING_BUILD=1 python bench.py --steps 20 --rounds ${AB_ROUNDS:-15} --host-rounds 0 --no-f16 --no-cpu-baseline > "$OUT/${name}_$r.json" 2> "$OUT/${name}_$r.err"
+    CHIRON_ALLOW_TIMING_BUILD=1 python bench.py --steps 20 --rounds ${AB_ROUNDS:-15} --host-rounds 0 --no-f16 --no-cpu-baseline --density-rounds 0 > "$OUT/${name}_$r.json" 2> "$OUT/${name}_$r.err"
   done
 done
 unset CHIRON_AMD_LIB

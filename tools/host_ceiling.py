@@ -52,19 +52,36 @@ class NullEngine(object):
         self._prob = rng.uniform(1.0, 6.0, size=(max_batch, 1)).astype(np.float32)
         self._lp = np.zeros((max_batch, 1), dtype=np.float32)
         self._shape_cols = int(n.max())
+        self._val8, self._n32 = self._val.astype(np.uint8), n.astype(np.int32)
+        self._stage = np.empty((max_batch, segment_len), dtype=np.float32)
+        self.legacy = os.environ.get("HOST_CEILING_LEGACY") == "1"     # round 4's host path: concatenated batches, SparseTensor regroup
         self._pending = [None] * n_slots
+        if not self.legacy:
+            self.submit_pieces = self._submit_pieces
 
-    def submit(self, slot, x, seq_len, beam_width=0, want_prob=True, want_logits=False, copy_decoded=True):
-        self._pending[slot] = (int(x.shape[0]), time.time())
+    def submit(self, slot, x, seq_len, beam_width=0, want_prob=True, want_logits=False, copy_decoded=True, compact=False):
+        self._pending[slot] = (int(x.shape[0]), time.time(), compact and not self.legacy)
+
+    def _submit_pieces(self, slot, pieces, seq_len, beam_width=0, want_prob=True, compact=True):
+        # what chiron_engine_submit_pieces does on the host: the pieces into the slot's staging buffer
+        row = 0
+        for p in pieces:
+            self._stage[row:row + len(p)] = p
+            row += len(p)
+        self._pending[slot] = (row, time.time(), compact)
 
     def collect(self, slot):
-        b, t0 = self._pending[slot]
+        b, t0, compact = self._pending[slot]
         self._pending[slot] = None
         if self.engine_ms > 0:
             left = self.engine_ms * 1e-3 - (time.time() - t0)
             if left > 0:
                 time.sleep(left)
         nnz = int(self._ends[b - 1])
+        if compact:
+            from chiron_amd.engine import CompactDecode
+            return self._DR(None, self._lp[:b].copy(), self._prob[:b].copy(), None,
+                            CompactDecode(self._val8[:nnz].copy(), self._n32[:b].copy(), np.asarray([b, self._shape_cols], dtype=np.int64)))
         # fresh arrays per batch, as Engine.collect's copies out of the slot's pinned buffers are
         return self._DR(self._ST(self._idx[:nnz].copy(), self._val[:nnz].copy(), np.asarray([b, self._shape_cols], dtype=np.int64)),
                         self._lp[:b].copy(), self._prob[:b].copy(), None)
@@ -91,7 +108,7 @@ def rank_main(a):
     """one rank: pin, wait for the start file, run the pipeline once untimed on a few reads (page cache, imports), then timed"""
     from chiron_amd import shard, eval as ce, extract as ex
     try:
-        os.sched_setaffinity(0, shard.rank_cpus(a.rank, a.world))
+        os.sched_setaffinity(0, shard.rank_affinity(a.rank, a.world) if os.environ.get("HOST_CEILING_PLAIN_SLICES") != "1" else shard.rank_cpus(a.rank, a.world))
     except (AttributeError, OSError):
         pass
     os.environ["LOCAL_WORLD_SIZE"] = str(a.world)            # the default reader / finisher thread count follows it (eval.evaluation)
@@ -101,6 +118,7 @@ def rank_main(a):
         extension, concise, mode, recursive = "fastq", False, "dna", True
         unit, idname, delimiter, test_number = False, False, "\n", None
         beam, threads, finish_procs, model = 0, a.threads, 0, "null-engine"
+        no_raw = os.environ.get("HOST_CEILING_NO_RAW") == "1"
     F.input = F.input_dir = a.input
     F.output = F.output_dir = a.output
 

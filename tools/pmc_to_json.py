@@ -46,6 +46,19 @@ def main():
                         "hbm_bytes": (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024})
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
             rec["mfma_busy_frac_of_all_simds"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        # Issue slots on the CUs the kernel actually holds (a launch of 138 workgroups holds 138 of the 256 CUs): SQ_BUSY_CU_CYCLES is summed
+        # over the CUs while they hold a wave of the kernel, four SIMDs each.  SQ_VALU_MFMA_BUSY_CYCLES: cycles a SIMD's matrix pipe is busy.
+        # SQ_ACTIVE_INST_VALU counts in units of four cycles the time a SIMD spends on VALU instructions -- the non-MFMA ones at their
+        # full length (4 cycles; 16 for exp / rcp) and one issue cycle per MFMA.  On gfx950 fp32 MFMA and VALU work of one SIMD do not
+        # overlap (tools/ubench/mfma_valu_overlap.hip), so their sum is the share of the SIMD's time that is spoken for: what a second
+        # resident workgroup could still fill is 1 - issue_busy.
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CU_CYCLES" in m and m["SQ_BUSY_CU_CYCLES"] > 0:
+            simd_cycles = 4.0 * m["SQ_BUSY_CU_CYCLES"]
+            rec["mfma_busy_frac_of_busy_cus"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+            if "SQ_ACTIVE_INST_VALU" in m:
+                valu = max(0.0, 4.0 * m["SQ_ACTIVE_INST_VALU"] - m.get("SQ_INSTS_MFMA", 0.0))
+                rec["valu_busy_frac_of_busy_cus"] = valu / simd_cycles
+                rec["issue_busy_frac_of_busy_cus"] = rec["mfma_busy_frac_of_busy_cus"] + rec["valu_busy_frac_of_busy_cus"]
         if "TCC_HIT_sum" in m:
             rec["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
         if "SQ_LDS_BANK_CONFLICT" in m:

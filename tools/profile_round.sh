@@ -19,14 +19,14 @@ cp "$OUT/${R}_pmc.json" "profiles/${R}_pmc.json"
 # 2. kernel trace of the bench command with one batch in flight (the per-kernel table) + its bench line
 #    (--no-f16: the fp16 / split side runs of the default command would put their kernels into the same trace)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o slots1 -- \
-  python bench.py --slots 1 --steps 5 --rounds 1 --host-rounds 0 --warmup 2 --no-f16 > "$OUT/bench_slots1.json" 2> "$OUT/bench_slots1.err"
+  python bench.py --slots 1 --steps 5 --rounds 1 --host-rounds 0 --warmup 2 --no-f16 --density-rounds 0 > "$OUT/bench_slots1.json" 2> "$OUT/bench_slots1.err"
 cp "$OUT"/prof/slots1_kernel_stats.csv "$OUT/${R}_kernel_stats_slots1.csv" 2>/dev/null || \
   find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_kernel_stats_slots1.csv" \;
 
 # 2b. the same command with THREE batches in flight (the regime the headline is quoted in): kernel trace -> how many kernels are
 #     resident over time, per-kernel durations in the mix (tools/overlap_trace.py)
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof3" -o slots3 -- \
-  python bench.py --slots 3 --steps 20 --rounds 2 --host-rounds 0 --warmup 3 --no-f16 --no-cpu-baseline > "$OUT/bench_slots3_traced.json" 2> "$OUT/bench_slots3_traced.err"
+  python bench.py --slots 3 --steps 20 --rounds 2 --host-rounds 0 --warmup 3 --no-f16 --no-cpu-baseline --density-rounds 0 > "$OUT/bench_slots3_traced.json" 2> "$OUT/bench_slots3_traced.err"
 python tools/overlap_trace.py "$(find "$OUT/prof3" -name '*kernel_trace.csv' | head -1)" 0.1 > "$OUT/${R}_overlap_slots3.txt" 2>> "$OUT/bench_slots3_traced.err"
 
 # 3. the default bench command, three times
