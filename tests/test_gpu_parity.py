@@ -1905,3 +1905,28 @@ def test_device_consensus_equals_host_vote(tmp_path):
         ce.evaluation(F)
         outs.append({n: open(os.path.join(F.output, "result", n)).read() for n in sorted(os.listdir(os.path.join(F.output, "result")))})
     assert outs[0] == outs[1] and len(outs[0]) == 3
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher (round-4 review, Missing #3): the script starts its own two ranks under
+    torch.distributed.run and rank 0 prints ONE line with "n_gpus": 2.  Both ranks on GPU 0 here (--share-gpu + gloo: the declared
+    self-test of the N > 1 path on a one-GPU box -- the line says so and is no measurement); without --share-gpu the same command
+    is refused on this box, because two ranks would compute on one device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--rounds", "1", "--host-rounds", "0", "--warmup", "1",
+              "--no-f16", "--no-cpu-baseline", "--density-rounds", "0"]
+    out = subprocess.run(common + ["--share-gpu", "--backend", "gloo"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["timed_steps"] == 4 and d["value"] > 0 and d["data"] == "synthetic"
+    assert abs(d["extra"]["windows_per_s"] - 2 * 4 * 1100 / d["timed_region_s"]) / d["extra"]["windows_per_s"] < 0.02     # whole-job aggregate
+    import torch
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run(common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
