@@ -402,7 +402,8 @@ def fit_emitting_head(weights, lasth, x, seq_len, bases_per_window, hidden=100, 
     Wc = (Wc * gain).astype(np.float32)
     bc0 = Y.mean(0) * gain
     core = (pre_all - mu).astype(np.float32) @ Wc          # [B, T, 5] without the class bias
-    lo, hi = -5.0 * logit_scale, 5.0 * logit_scale        # density falls as the blank bias rises
+    span = 2.0 * float(np.abs(core).max()) + float(np.abs(bc0).max()) + 1.0
+    lo, hi = -span, span                                  # density falls as the blank bias rises; beyond +-span nothing changes
     for _ in range(40):
         mid = 0.5 * (lo + hi)
         b = bc0.copy()

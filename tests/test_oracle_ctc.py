@@ -211,3 +211,51 @@ def test_beam_scores_against_torch_ctc_forward_algorithm(built):
                 assert (plp[:, 0] <= pex + 1e-9).all()
                 if T == 3:
                     assert np.abs(plp[:, 0] - pex).max() < 1e-9
+
+
+def test_greedy_base_count_equals_the_oracle_decode_lengths():
+    """model.greedy_base_count (used by fit_emitting_head to bisect a head's blank bias, and by bench.py's realistic-density leg) counts
+    what tf.nn.ctc_greedy_decoder emits: the oracle's greedy decode, row by row, ragged lengths included."""
+    import chiron_amd as ca
+    rng = np.random.RandomState(3)
+    for _ in range(20):
+        B, T = int(rng.randint(1, 9)), int(rng.randint(1, 40))
+        lg = rng.normal(0, 2, (B, T, 5)).astype(np.float32)
+        lg[..., 4] += rng.choice([-2.0, 0.0, 3.0])
+        sl = rng.randint(0, T + 1, size=B)
+        rows, _ = co.greedy_decode(lg, sl)
+        assert ca.greedy_base_count(lg, sl).tolist() == [len(r) for r in rows]
+
+
+def test_fit_emitting_head_reaches_the_requested_density():
+    """model.fit_emitting_head: a recurrent output that encodes the squiggle's level changes (here: planted, plus noise) under the fitted
+    head decodes the requested number of bases per window, on the calibration windows and on held-out ones; only the four head tensors
+    of the weight dict change."""
+    import chiron_amd as ca
+    rng = np.random.RandomState(11)
+    B, T, H = 24, 200, 100
+    x = np.zeros((B, T), dtype=np.float32)
+    for b in range(B):                                  # a squiggle: a new level every ~9 samples
+        t = 0
+        while t < T:
+            n = int(rng.geometric(1.0 / 9.0))
+            x[b, t:t + n] = rng.normal(500, 80)
+            t += n
+    x += rng.normal(0, 4, x.shape).astype(np.float32)
+    jump = np.abs(np.diff(x, axis=1, prepend=x[:, :1])) > 32
+    q = np.searchsorted(np.quantile(x, [0.25, 0.5, 0.75]), x)
+    proj = rng.normal(0, 1, (6, 2 * H))
+    feat = np.stack([jump * (q == k) for k in range(4)] + [~jump, np.ones_like(jump)], axis=-1).astype(np.float64)
+    h = np.tanh(feat @ proj + rng.normal(0, 0.05, (B, T, 2 * H)))
+    w = {"rnn_fnn_layer/weights": np.zeros((2, H), np.float32), "rnn_fnn_layer/bias": np.zeros(H, np.float32),
+         "rnn_fnn_layer/weights_class": np.zeros((H, 5), np.float32), "rnn_fnn_layer/bias_class": np.zeros(5, np.float32), "other": np.ones(3)}
+    sl = np.full(B, T)
+    out = ca.fit_emitting_head(w, h[:16], x[:16], sl[:16], 12.0, hidden=H)
+    assert out["other"] is w["other"] and set(out) == set(w)
+
+    def density(rows):
+        pre = (h[rows, :, :H] * out["rnn_fnn_layer/weights"][0] + h[rows, :, H:] * out["rnn_fnn_layer/weights"][1]) + out["rnn_fnn_layer/bias"]
+        lg = pre @ out["rnn_fnn_layer/weights_class"] + out["rnn_fnn_layer/bias_class"]
+        return ca.greedy_base_count(lg, sl[rows]).mean()
+
+    assert abs(density(slice(0, 16)) - 12.0) < 0.5 and abs(density(slice(16, 24)) - 12.0) < 3.0

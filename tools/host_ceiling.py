@@ -115,7 +115,7 @@ def rank_main(a):
 
     class F(object):
         start, segment_len, jump, batch_size = 0, 400, 390, a.batch
-        extension, concise, mode, recursive = "fastq", False, "dna", True
+        extension, concise, mode, recursive = "fastq", os.environ.get("HOST_CEILING_CONCISE") == "1", "dna", True
         unit, idname, delimiter, test_number = False, False, "\n", None
         beam, threads, finish_procs, model = 0, a.threads, 0, "null-engine"
         no_raw = os.environ.get("HOST_CEILING_NO_RAW") == "1"
