@@ -228,6 +228,12 @@ def test_signal_text_writer_and_extract_records(tmp_path):
     assert np.array_equal(recs[0][1], signal_io.read_signal(SIG))
     F.mode = "rna"
     assert np.array_equal(extract.extract_records(F5, F)[0][1], recs[0][1][::-1])
+    # `chiron call --no-raw` (opt-in deviation, DESIGN appendix D Q28): the samples come back, raw/<name>.signal is not written; the
+    # two-pass path (--via-signal-files) reads that file back, so entry.evaluation switches the option off there
+    F.mode, F.no_raw = "dna", True
+    os.remove(os.path.join(F.raw_folder, "read1.signal"))
+    again = extract.extract_records(F5, F)
+    assert np.array_equal(again[0][1], recs[0][1]) and os.listdir(F.raw_folder) == []
 
 
 def test_native_reader_with_and_without_libdeflate(tmp_path):
