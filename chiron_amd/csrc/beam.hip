@@ -317,6 +317,8 @@ __device__ __forceinline__ float wave_min(float v) {
   v = fminf(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
   v = fminf(v, dpp_f<0x141>(v));  // row_half_mirror
   v = fminf(v, dpp_f<0x140>(v));  // row_mirror: every lane of a 16-lane row holds the row minimum
+  // (the same reduction with v_permlane16_swap + v_permlane32_swap instead of the four v_readlane was measured in round 5: 2.84 against
+  //  2.75 ms alone at W = 50, the same in the mix -- the wave-uniform result in an SGPR is worth more than the two instructions)
   return fminf(fminf(rlf(v, 0), rlf(v, 16)), fminf(rlf(v, 32), rlf(v, 48)));
 }
 
@@ -709,8 +711,13 @@ __device__ __forceinline__ float half_min(float v) {   // minimum over the 32 la
   v = fminf(v, dpp_f<0xB1>(v));
   v = fminf(v, dpp_f<0x4E>(v));
   v = fminf(v, dpp_f<0x141>(v));
-  v = fminf(v, dpp_f<0x140>(v));
-  return fminf(v, __shfl_xor(v, 16));
+  v = fminf(v, dpp_f<0x140>(v));   // every lane of a 16-lane row holds its row's minimum
+  // the neighbouring row's value without the LDS crossbar (round 5: was __shfl_xor(v, 16), a ds_bpermute round trip in every bottom()):
+  // v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second -- with both operands v the results
+  // are (row0, row0, row2, row2) and (row1, row1, row3, row3)
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fminf(__uint_as_float(t[0]), __uint_as_float(t[1]));
 }
 
 __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int node_cap) {
@@ -846,13 +853,19 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
         const bool hev = evh != 0u;                                  // this half has an event in this iteration
         const int i = __builtin_ctz(evh | 0x80000000u);              // its branch (slot in the half)
         const int src = hb + i;
-        const int c = __shfl(__builtin_ctz(ev | 16u), src) & 3;
-        const bool ins = hev && ((__shfl((int)cnd, src) >> c) & 1);
+        // every lane prepares what it would report as the event's branch -- its first pending label, whether that is an insertion, the
+        // candidate's total and the child's slot -- BEFORE the broadcast: three independent ds_bpermute instead of two dependent rounds
+        // (label first, then the values selected with it) plus a third for the candidate set (round 5)
+        const int c_own = __builtin_ctz(ev | 16u) & 3;
+        const int pk_own = c_own | ((int)((cnd >> c_own) & 1u) << 2);
+        const float tot_own = c_own == 0 ? cand[0] : c_own == 1 ? cand[1] : c_own == 2 ? cand[2] : cand[3];
+        const int co_own = c_own == 0 ? chs[0] : c_own == 1 ? chs[1] : c_own == 2 ? chs[2] : chs[3];
+        const int pk = __shfl(pk_own, src);
+        const float tot = __shfl(tot_own, src);     // node id, parent node and depth of a new leaf: once per frame, after the walk (beam64_kernel)
+        const int co = __shfl(co_own, src);
+        const int c = pk & 3;
+        const bool ins = hev && ((pk >> 2) & 1);
         const bool rs = hev && !ins;
-        const float sel_tot = c == 0 ? cand[0] : c == 1 ? cand[1] : c == 2 ? cand[2] : cand[3];
-        const int sel_co = c == 0 ? chs[0] : c == 1 ? chs[1] : c == 2 ? chs[2] : chs[3];
-        const float tot = __shfl(sel_tot, src);     // node id, parent node and depth of a new leaf: once per frame, after the walk (beam64_kernel)
-        const int co = __shfl(sel_co, src);
         // insertion: the bottom leaves the search (full) or the leaves grow by one
         const int slot = full ? boti : nL;
         const int jo = __shfl(l_orig, hb + (slot & 31));
