@@ -68,8 +68,8 @@ SYMBOLS = [
     ("chiron_engine_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("chiron_engine_submit", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_uint32]),
-    ("chiron_engine_submit_pieces", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
-                                              C.c_int32, C.c_int32, C.c_uint32]),
+    ("chiron_engine_submit_pieces", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                              C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32]),
     ("chiron_engine_decode", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_uint32]),
     ("chiron_engine_collect", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Decoded)]),

@@ -1553,30 +1553,33 @@ static void resync_tile_counters(Slot* s) {
 }
 
 static chiron_status submit_impl(chiron_engine* e, int32_t slot, const float* x, const float* const* pieces, const int32_t* piece_rows,
-                                 int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width, uint32_t flags);
+                                 const int64_t* piece_row_stride, int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width,
+                                 uint32_t flags);
 
 extern "C" chiron_status chiron_engine_submit(chiron_engine* e, int32_t slot, const float* x, const int32_t* seq_len,
                                               int32_t batch, int32_t beam_width, uint32_t flags) {
   if (!x) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
-  return submit_impl(e, slot, x, nullptr, nullptr, 0, seq_len, batch, beam_width, flags);
+  return submit_impl(e, slot, x, nullptr, nullptr, nullptr, 0, seq_len, batch, beam_width, flags);
 }
 
 extern "C" chiron_status chiron_engine_submit_pieces(chiron_engine* e, int32_t slot, const float* const* pieces, const int32_t* piece_rows,
-                                                     int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width,
-                                                     uint32_t flags) {
+                                                     const int64_t* piece_row_stride, int32_t n_pieces, const int32_t* seq_len, int32_t batch,
+                                                     int32_t beam_width, uint32_t flags) {
   if (!pieces || !piece_rows || n_pieces < 1) return fail(CHIRON_ERR_INVALID, "null / empty piece list");
   if (flags & CHIRON_X_ON_DEVICE) return fail(CHIRON_ERR_INVALID, "chiron_engine_submit_pieces takes host pieces");
   long rows = 0;
   for (int i = 0; i < n_pieces; ++i) {
     if (!pieces[i] || piece_rows[i] < 0) return fail(CHIRON_ERR_INVALID, "piece %d: null pointer or negative row count", i);
+    if (piece_row_stride && piece_row_stride[i] < 1) return fail(CHIRON_ERR_INVALID, "piece %d: row stride %lld", i, (long long)piece_row_stride[i]);
     rows += piece_rows[i];
   }
   if (rows != batch) return fail(CHIRON_ERR_INVALID, "the pieces hold %ld rows, batch is %d", rows, batch);
-  return submit_impl(e, slot, nullptr, pieces, piece_rows, n_pieces, seq_len, batch, beam_width, flags);
+  return submit_impl(e, slot, nullptr, pieces, piece_rows, piece_row_stride, n_pieces, seq_len, batch, beam_width, flags);
 }
 
 static chiron_status submit_impl(chiron_engine* e, int32_t slot, const float* x, const float* const* pieces, const int32_t* piece_rows,
-                                 int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width, uint32_t flags) {
+                                 const int64_t* piece_row_stride, int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width,
+                                 uint32_t flags) {
   if (!e) return fail(CHIRON_ERR_INVALID, "null engine");
   if (slot < 0 || slot >= (int)e->slots.size()) return fail(CHIRON_ERR_STATE, "slot %d out of range (%zu slots)", slot, e->slots.size());
   if (!seq_len) return fail(CHIRON_ERR_INVALID, "null x/seq_len");
@@ -1603,7 +1606,12 @@ static chiron_status submit_impl(chiron_engine* e, int32_t slot, const float* x,
       } else {   // cross-read packing (chiron_eval.py:321-334) straight into the staging buffer: the batch is never assembled anywhere else
         size_t row = 0;
         for (int i = 0; i < n_pieces; ++i) {
-          memcpy(s->h_sig + row * e->L, pieces[i], (size_t)piece_rows[i] * e->L * 4);
+          const int64_t stride = piece_row_stride ? piece_row_stride[i] : e->L;
+          if (stride == e->L) {
+            memcpy(s->h_sig + row * e->L, pieces[i], (size_t)piece_rows[i] * e->L * 4);
+          } else {   // windows of one signal buffer: row r starts r * jump samples in and overlaps its neighbour (chiron_input.py:276-286)
+            for (int r = 0; r < piece_rows[i]; ++r) memcpy(s->h_sig + (row + r) * e->L, pieces[i] + (size_t)r * stride, (size_t)e->L * 4);
+          }
           row += piece_rows[i];
         }
       }

@@ -137,14 +137,17 @@ class Engine(object):
         n = len(pieces)
         ptrs = (C.c_void_p * n)()
         rows = (C.c_int32 * n)()
+        strides = (C.c_int64 * n)()
         for i, a in enumerate(pieces):
-            if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] != self.segment_len or not a.flags["C_CONTIGUOUS"]:
-                raise ValueError("piece %d must be a C-contiguous float32 [n, %d] array" % (i, self.segment_len))
+            if not piece_ok(a, self.segment_len):
+                raise ValueError("piece %d must be a float32 [n, %d] array with contiguous rows (row stride any positive multiple of 4 bytes: "
+                                 "windows of one signal buffer are welcome)" % (i, self.segment_len))
             ptrs[i] = a.ctypes.data
             rows[i] = a.shape[0]
+            strides[i] = a.strides[0] // 4 if a.shape[0] > 1 else self.segment_len
         seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
         flags = (_lib.WANT_PROB if want_prob else 0) | (_lib.COMPACT_DECODE if compact else 0)
-        _lib.check(self._lib.chiron_engine_submit_pieces(self._h, slot, ptrs, rows, n, seq_len.ctypes.data_as(C.c_void_p),
+        _lib.check(self._lib.chiron_engine_submit_pieces(self._h, slot, ptrs, rows, strides, n, seq_len.ctypes.data_as(C.c_void_p),
                                                          int(seq_len.shape[0]), int(beam_width), flags))
         self._keep[slot] = (pieces, seq_len)
 
@@ -249,6 +252,13 @@ class Engine(object):
             s = arr[i]
             out[s.name.decode()] = {"total_ms": s.total_ms, "launches": s.launches, "flops": s.flops, "bytes": s.bytes}
         return out
+
+
+def piece_ok(a, segment_len):
+    """what Engine.submit_pieces takes as one piece: float32 [n, segment_len], every row contiguous, rows any positive whole number of
+    floats apart (C-contiguous arrays, row slices of them, and the overlapping windows signal_io.window_signal returns)"""
+    return (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == segment_len and a.strides[1] == 4
+            and (a.shape[0] <= 1 or (a.strides[0] > 0 and a.strides[0] % 4 == 0)))
 
 
 def calibration_windows(segment_len, n, ratio, seed=20260928):

@@ -20,7 +20,7 @@ import numpy as np
 from . import assembly
 from . import model as model_mod
 from . import signal_io
-from .engine import Engine, SparseTensor, seq_len_for_engine
+from .engine import Engine, SparseTensor, seq_len_for_engine, piece_ok
 from .unix_time import unix_time
 
 BASES = "ACGT"
@@ -294,7 +294,7 @@ class BatchPacker(object):
 
     def _emit(self, n_valid):
         sl = np.concatenate(self.sl, axis=0)
-        if n_valid == self.batch_size and all(p.dtype == np.float32 and p.flags["C_CONTIGUOUS"] for p in self.x):
+        if n_valid == self.batch_size and all(piece_ok(p, self.segment_len) for p in self.x):
             # a full batch: hand the per-run arrays on as they are (row slices of the reads' window arrays)
             b = Batch(None, seq_len_for_engine(sl, self.ratio), self.runs, n_valid, rows=n_valid, pieces=self.x)
             self._reset()

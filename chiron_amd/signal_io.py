@@ -2,6 +2,8 @@
 chiron/chiron_input.py: read_signal :527-539, read_signal_fast5 :541-555,
 read_data_for_eval :253-292, padding :681-692, DataSet.next_batch eval branch
 :194-250).  numpy arrays instead of Python lists; same values."""
+import os
+
 import numpy as np
 
 MEDIAN = 0          # chiron_input.py:30-31
@@ -71,15 +73,19 @@ def window_signal(signal, start_index, step, seg_length):
     zero padded (padding(), :681-692).  -> (event float32 [n_win, L], event_length int32 [n_win])."""
     sig = np.asarray(signal, dtype=np.float32)[start_index:]
     n = sig.shape[0]
-    starts = np.arange(0, n, step)
-    ev = np.zeros((len(starts), seg_length), dtype=np.float32)
-    ln = np.minimum(n - starts, seg_length).astype(np.int32)
-    full = ln == seg_length
-    if full.any():
-        idx = starts[full][:, None] + np.arange(seg_length)[None, :]
-        ev[full] = sig[idx]
-    for j in np.nonzero(~full)[0]:
-        ev[j, :ln[j]] = sig[starts[j]:starts[j] + ln[j]]
+    n_win = -(-n // step) if n > 0 else 0
+    ln = np.minimum(n - step * np.arange(n_win), seg_length).astype(np.int32)
+    if n_win == 0:
+        return np.zeros((0, seg_length), dtype=np.float32), ln
+    # ONE zero-padded copy of the signal; the windows are overlapping VIEWS of it (row r starts r * step samples in): nothing is
+    # gathered -- the engine copies row by row into its staging buffer (chiron_engine_submit_pieces with row stride = step), and
+    # np.concatenate / slicing / comparison see an ordinary [n_win, seg_length] array.  Read-only, because rows share memory.
+    buf = np.zeros((n_win - 1) * step + seg_length, dtype=np.float32)
+    m = min(n, buf.shape[0])           # jump > seg_length: the samples between the last window's end and the signal's are in no window
+    buf[:m] = sig[:m]
+    ev = np.lib.stride_tricks.as_strided(buf, shape=(n_win, seg_length), strides=(step * 4, 4), writeable=False)
+    if os.environ.get("CHIRON_WINDOW_COPY"):      # A/B switch: materialise the windows as rounds 1 .. 4 did (a [n_win, seg_length] copy per read)
+        ev = np.ascontiguousarray(ev)
     return ev, ln
 
 

@@ -196,12 +196,16 @@ typedef struct {
   const int32_t* row_counts;
 } chiron_decoded;
 
-/* chiron_engine_submit with the batch given as `n_pieces` host arrays of whole rows (piece i: piece_rows[i] x segment_len floats,
- * rows summing to `batch`): the cross-read packing of chiron_eval.py:321-334 -- the tail of one read, whole reads, the head of
- * the next -- copied straight into the slot's pinned staging buffer, so the caller never assembles the [batch, segment_len]
- * array (1.76 MB per 1100-window batch on the host's main thread otherwise).  Host pointers only.                        */
+/* chiron_engine_submit with the batch given as `n_pieces` host arrays of whole rows (piece i: piece_rows[i] rows of segment_len
+ * floats, rows summing to `batch`): the cross-read packing of chiron_eval.py:321-334 -- the tail of one read, whole reads, the
+ * head of the next -- copied straight into the slot's pinned staging buffer, so the caller never assembles the [batch,
+ * segment_len] array (1.76 MB per 1100-window batch on the host's main thread otherwise).  piece_row_stride[i] (floats; NULL =
+ * segment_len everywhere) is the distance between consecutive rows of piece i: with stride = jump the rows ARE the windows
+ * signal[r*jump : r*jump + segment_len] of one zero-padded signal buffer (chiron_input.py:276-286) and the host never
+ * materialises the windowed read either.  Host pointers only.                                                            */
 chiron_status chiron_engine_submit_pieces(chiron_engine* e, int32_t slot, const float* const* pieces, const int32_t* piece_rows,
-                                          int32_t n_pieces, const int32_t* seq_len, int32_t batch, int32_t beam_width, uint32_t flags);
+                                          const int64_t* piece_row_stride, int32_t n_pieces, const int32_t* seq_len, int32_t batch,
+                                          int32_t beam_width, uint32_t flags);
 
 /* Replaces sess.run(decode dequeue) (chiron_eval.py:403-409).  Blocks until the
  * slot's work is complete, then fills *out with host pointers owned by the slot. */

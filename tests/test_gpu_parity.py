@@ -1682,6 +1682,12 @@ def test_compact_decode_and_piecewise_submit_equal_the_sparse_tensor_path(dna, b
         assert np.array_equal(got.log_prob, ref.log_prob) and np.array_equal(got.prob_logits, ref.prob_logits)
         again = eng.infer(x, sl, beam_width=beam, want_prob=True, slot=1)          # the plain form on the same slot afterwards
         assert again.compact is None and np.array_equal(again.decoded.values, ref.decoded.values) and np.array_equal(again.decoded.indices, ref.decoded.indices)
+        # the windows as signal_io.window_signal hands them out: overlapping read-only VIEWS of one zero-padded signal buffer (row
+        # stride = jump samples) -- submit_pieces copies row by row, the windowed read is never materialised on the host
+        xv, _ = _windows(jump * (n - 1) + 200, L, jump, seed=91)
+        assert not xv.flags["C_CONTIGUOUS"] and xv.strides == (jump * 4, 4) and np.array_equal(xv, x)
+        eng.submit_pieces(1, [xv[:60], xv[60:61], xv[61:]], sl, beam_width=beam, want_prob=True, compact=True)
+        assert np.array_equal(eng.collect(1).compact.flat, c.flat)
         eng.submit(0, x, sl, beam_width=beam, compact=True)                       # compact without pieces
         assert np.array_equal(eng.collect(0).compact.flat, c.flat)
         with pytest.raises(_lib.ChironError):
