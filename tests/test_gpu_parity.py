@@ -18,7 +18,8 @@ TOL = 1e-4
 def _windows(n_samples, L, jump, seed):
     from chiron_amd import signal_io
     sig = ca.synthetic_signal(1, n_samples, seed=seed)[0]
-    return signal_io.window_signal(sig, 0, jump, L)
+    ev, ln = signal_io.window_signal(sig, 0, jump, L)
+    return np.array(ev), ln          # a private, writable copy (window_signal hands out read-only overlapping views; tests edit rows)
 
 
 def _check_decode(res, logits, sl, B):
@@ -1684,8 +1685,9 @@ def test_compact_decode_and_piecewise_submit_equal_the_sparse_tensor_path(dna, b
         assert again.compact is None and np.array_equal(again.decoded.values, ref.decoded.values) and np.array_equal(again.decoded.indices, ref.decoded.indices)
         # the windows as signal_io.window_signal hands them out: overlapping read-only VIEWS of one zero-padded signal buffer (row
         # stride = jump samples) -- submit_pieces copies row by row, the windowed read is never materialised on the host
-        xv, _ = _windows(jump * (n - 1) + 200, L, jump, seed=91)
-        assert not xv.flags["C_CONTIGUOUS"] and xv.strides == (jump * 4, 4) and np.array_equal(xv, x)
+        from chiron_amd import signal_io
+        xv, _ = signal_io.window_signal(ca.synthetic_signal(1, jump * (n - 1) + 200, seed=91)[0], 0, jump, L)
+        assert not xv.flags["C_CONTIGUOUS"] and not xv.flags["WRITEABLE"] and xv.strides == (jump * 4, 4) and np.array_equal(xv, x)
         eng.submit_pieces(1, [xv[:60], xv[60:61], xv[61:]], sl, beam_width=beam, want_prob=True, compact=True)
         assert np.array_equal(eng.collect(1).compact.flat, c.flat)
         eng.submit(0, x, sl, beam_width=beam, compact=True)                       # compact without pieces

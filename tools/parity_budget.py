@@ -38,7 +38,7 @@ def windows(n_samples, L, jump, seed):
     from chiron_amd import signal_io
     sig = ca.synthetic_signal(1, n_samples, seed=seed)[0]
     ev, ln = signal_io.window_signal(sig, 0, jump, L)
-    return np.asarray(ev, dtype=np.float32), np.asarray(ln, dtype=np.int64)
+    return np.array(ev, dtype=np.float32), np.asarray(ln, dtype=np.int64)      # a writable copy: window_signal's rows are read-only views
 
 
 def stats(a, b, mask=None):
