@@ -556,10 +556,13 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
     # packs batches and talks to the engine.  Batches are packed in file order, so results do not depend on timing.
     n_threads = int(getattr(FLAGS, "threads", 0) or 0)
     if n_threads <= 0:
-        # default: a quarter of this rank's share of the host's cores, between 4 and 12 (behind the fp16 engine the fast5 side --
-        # inflate + the raw/*.signal copy of every read -- needs 6 .. 8 reader threads to keep up; 8 ranks on a 128-core node: 4)
+        # default: a quarter of this rank's share of the host's cores, between 4 and 6.  Round 5 measured, on a 2 x 64-core host: behind
+        # the null engine one rank moves 540 / 800 / 700 / 670 / 560 k windows/s with 2 / 4 / 8 / 12 / 24 reader + finisher threads (more
+        # threads = more interpreter-lock hand-overs, not more work done: the native calls are short), eight ranks 2.6 / 2.3 / 2.2 M with
+        # 4 / 8 / 16; behind the real fp16 engine at batch 4096 with raw/*.signal written: 4 threads 17 .. 19 Mbases/s (too few while a
+        # thread sits in a 0.4 MB text write), 6 threads 24.2 / 24.5, 12 threads 24.3 / 13.3 (unstable).  -t overrides.
         ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
-        n_threads = min(12, max(4, (os.cpu_count() or 16) // (4 * ranks_here)))
+        n_threads = min(6, max(4, (os.cpu_count() or 16) // (4 * ranks_here)))
     readers = ThreadPoolExecutor(max_workers=n_threads)
     # Finishing (base strings, consensus vote, quality string, three files per read) is Python + numpy + native calls: as
     # threads it is bound by the GIL at a few hundred reads per second, enough for the fp32 engine.  FLAGS.finish_procs > 0
