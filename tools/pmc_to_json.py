@@ -49,9 +49,9 @@ def main():
         # Issue slots on the CUs the kernel actually holds (a launch of 138 workgroups holds 138 of the 256 CUs): SQ_BUSY_CU_CYCLES is summed
         # over the CUs while they hold a wave of the kernel, four SIMDs each.  SQ_VALU_MFMA_BUSY_CYCLES: cycles a SIMD's matrix pipe is busy.
         # SQ_ACTIVE_INST_VALU counts in units of four cycles the time a SIMD spends on VALU instructions -- the non-MFMA ones at their
-        # full length (4 cycles; 16 for exp / rcp) and one issue cycle per MFMA.  On gfx950 fp32 MFMA and VALU work of one SIMD do not
-        # overlap (tools/ubench/mfma_valu_overlap.hip), so their sum is the share of the SIMD's time that is spoken for: what a second
-        # resident workgroup could still fill is 1 - issue_busy.
+        # full length (4 cycles; 16 for exp / rcp) and one issue cycle per MFMA.  In a saturated MFMA stream VALU work of a partner wave
+        # adds to the stream's time (tools/ubench/mfma_valu_overlap.hip); in a kernel with idle gaps the two counters may overlap, so their
+        # sum is an UPPER bound of the SIMD time that is spoken for (DESIGN 3.9 has the direct measurement for the recurrence).
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CU_CYCLES" in m and m["SQ_BUSY_CU_CYCLES"] > 0:
             simd_cycles = 4.0 * m["SQ_BUSY_CU_CYCLES"]
             rec["mfma_busy_frac_of_busy_cus"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
