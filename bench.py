@@ -99,18 +99,22 @@ def main():
                     "~43.9 bases per window, as a trained model does); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=0, help="windows for the CPU baseline (0 = auto)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu is a self-test of the "
-                    "N>1 code path on a box with one GPU (not a valid measurement)")
+    ap.add_argument("--backend", default="gloo", choices=("gloo", "nccl"),
+                    help="torch.distributed backend of the BOOKKEEPING (two barriers, a MAX of the clocks, a SUM of two counters: 24 "
+                         "bytes in all).  The data path has no collective (north_star: 'no RCCL collectives'), so the default is gloo "
+                         "on CPU tensors: the N-GPU record does not depend on RCCL bring-up.  'nccl' (= RCCL) stays selectable; when "
+                         "its initialisation raises, the ranks fall back to gloo together and config.parallelism_bookkeeping says so")
     ap.add_argument("--share-gpu", action="store_true", help="self-test only: every rank uses GPU 0")
     ap.add_argument("--no-f16", action="store_true", help="skip the extra measurements (configs[4]: fp16 batch 4096; fp32-split dtype)")
     ap.add_argument("--stub-engine", type=float, default=0.0, metavar="MS",
                     help="self-test of the multi-rank bookkeeping WITHOUT a GPU (tests/test_bench_ranks.py): the engine is replaced "
-                         "by a stub whose collect() takes MS + rank milliseconds; implies --backend gloo.  Never a measurement: the "
+                         "by a stub whose collect() takes MS + rank milliseconds (with --backend nccl it exercises the fall-back to "
+                         "gloo: there is no RCCL without a GPU).  Never a measurement: the "
                          "line says data = 'stub'.")
     args = ap.parse_args()
     stub = args.stub_engine > 0
     if stub:
-        args.backend, args.no_f16, args.no_cpu_baseline, args.density_rounds = "gloo", True, True, 0
+        args.no_f16, args.no_cpu_baseline, args.density_rounds = True, True, 0
 
     # `--gpus N` is the contract: N ranks, one per GPU.  Started bare (no WORLD_SIZE: the way the 1-GPU line is started), the
     # script starts its own N ranks under torch.distributed.run and rank 0's line is the record; started under a launcher
@@ -136,21 +140,22 @@ def main():
             sys.stderr.write("bench.py: rank %d wants GPU %d, this node shows %d\n" % (rank, local_rank, torch.cuda.device_count()))
             sys.exit(3)
         torch.cuda.set_device(local_rank)
+    bookkeeping, grp = "none (one rank)", None
+    idents = [device_identity(torch, local_rank) if not stub else "stub:%d" % device_ordinal]
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-    cdev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # where collectives run
+        bookkeeping, grp = init_bookkeeping(dist, torch, args.backend, local_rank)
+    cdev = torch.device("cuda", local_rank) if bookkeeping.startswith("nccl") else torch.device("cpu")   # where the reductions run
     if world > 1:
         # one rank per device: every rank reports the device it computes on (the GPU's PCI address; the ordinal for the stub) and
         # all of them must differ -- eight ranks on one GPU would still print a line (--share-gpu is the declared self-test)
-        ident = device_identity(torch, local_rank) if not stub else "stub:%d" % device_ordinal
+        ident = idents[0]
         idents = [None] * world
         dist.all_gather_object(idents, ident)
         if not args.share_gpu and ranks_share_a_device(idents, world if stub else torch.cuda.device_count()):
             sys.stderr.write("bench.py: ranks share a device: %s\n" % idents)
             sys.exit(4)
+    # the record itself proves N distinct GPUs: rank r -> "uuid/pci domain/bus/device" + ordinal as torch reports them
+    devices = [i if isinstance(i, str) else {"rank": r, "ordinal": i[1], "hardware": i[0]} for r, i in enumerate(idents)]
 
     import chiron_amd as ca
     from chiron_amd import assembly
@@ -222,7 +227,7 @@ def main():
     decoded_bases[0] = consensus_bases[0] = 0
 
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=grp)
     device_sync()
     t0 = time.perf_counter()
     timed_steps = args.steps * max(1, args.rounds)
@@ -232,14 +237,14 @@ def main():
     eng.sync()
     device_sync()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=grp)
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp)
         dt = float(tt.item())
         agg = torch.tensor([decoded_bases[0], consensus_bases[0]], dtype=torch.float64, device=cdev)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM, group=grp)
         decoded_bases[0], consensus_bases[0] = int(agg[0].item()), int(agg[1].item())
 
     windows = timed_steps * BATCH * world
@@ -268,7 +273,7 @@ def main():
         drain(pending)
         eng.sync()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=grp)
         device_sync()
         h0 = time.perf_counter()
         host_steps = args.steps * args.host_rounds
@@ -278,11 +283,11 @@ def main():
         eng.sync()
         device_sync()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=grp)
         hdt = time.perf_counter() - h0
         if world > 1:
             tt = torch.tensor([hdt], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=grp)
             hdt = float(tt.item())
         host_inclusive = {"kbases_per_s": round(host_steps * BATCH * world * BASES_PER_WINDOW / 1000.0 / hdt, 2),
                           "ms_per_step": round(hdt / host_steps * 1e3, 3), "timed_steps": host_steps, "timed_region_s": round(hdt, 3),
@@ -301,7 +306,7 @@ def main():
         out = {"metric": "kilobases/sec basecalled (DNA_default seg_len=400 batch=1100)", "value": round(value, 2), "unit": "kbases/s",
                "n_gpus": world, "steps": args.steps, "rounds": max(1, args.rounds), "timed_steps": timed_steps, "timed_region_s": round(dt, 3),
                "warmup": args.warmup, "ms_per_step": round(dt / timed_steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "stub", "config": {"workload": "SELF-TEST: stub engine, not a measurement"},
+               "vs_baseline": None, "dtype": "f32", "data": "stub", "config": {"workload": "SELF-TEST: stub engine, not a measurement", "parallelism_bookkeeping": bookkeeping, "devices": devices},
                "roofline": None, "cpu_baseline": None,
                "extra": {"windows_per_s": round(windows / dt, 1), "decoded_bases_total": decoded_total, "host_inclusive": host_inclusive}}
     elif rank == 0:
@@ -373,7 +378,10 @@ def main():
             "config": {"workload": "DNA_default seg_len=400 jump=390 batch=1100 greedy, synthetic 4 kHz signal "
                                    "(BASELINE.json configs[1])", "segment_len": SEG_LEN, "jump": JUMP,
                        "batch": BATCH, "decode": "greedy", "weights": "seeded synthetic (exact checkpoint shapes)",
-                       "parallelism": "reads sharded per GPU, no collective", "slots_in_flight": args.slots},
+                       "parallelism": "reads sharded per GPU, no collective", "slots_in_flight": args.slots,
+                       # what carries the two barriers + the 24 bytes of timing / counter reductions around the timed region
+                       "parallelism_bookkeeping": bookkeeping, "devices": devices,
+                       "distinct_devices": len(set(d["hardware"] for d in devices)) if not args.share_gpu else 1},
             "roofline": roofline, "cpu_baseline": cpu,
             "extra": {"windows_per_s": round(windows / dt, 1),
                       "decoded_bases_per_s": round(decoded_total / dt, 1),
@@ -395,7 +403,7 @@ def main():
         out["extra"]["config5_f16_w2"] = f16_config(spec, weights, x_dev, s_dev, ref32, local_rank, dtype="fp16-w2")
         out["extra"]["f32_split_dtype"] = split_config(spec, weights, x_dev, s_dev, ref32, local_rank)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=grp)
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
@@ -460,6 +468,30 @@ def density_region(args, spec, device_id, x_dev, s_dev, xb, lb, step, drain, dec
             "half_precision_engines_vs_fp32_greedy_strings": halves,
             "weights": "the headline's synthetic weights with LSTM forget biases -3 and an FC head fitted (model.fit_emitting_head) on 256 "
                        "windows to emit 43.875 bases per window; same step as the headline: submit, collect (SparseTensor D2H), per-read glue vote"}
+
+
+def init_bookkeeping(dist, torch, backend, local_rank):
+    """Process group(s) for the bookkeeping around the timed region (never the data path) -> (description, group for the reductions).
+    The default group is ALWAYS gloo (CPU tensors).  With --backend nccl a second, RCCL group carries the barriers and reductions --
+    if its creation or first collective raises on ANY rank (the ranks agree over gloo), every rank stays on gloo and the line says so."""
+    dist.init_process_group("gloo")
+    what = "2 barriers + all_reduce MAX of the clock + SUM of two counters per region"
+    if backend != "nccl":
+        return "gloo (cpu tensors): " + what, None
+    err, grp = None, None
+    try:
+        grp = dist.new_group(backend="nccl")
+        dist.all_reduce(torch.zeros(1, device=torch.device("cuda", local_rank)), group=grp)   # RCCL's communicator is created lazily: force it now
+        torch.cuda.synchronize()
+    except Exception as e:                                                            # noqa: BLE001 -- whatever bring-up raises
+        err = "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0][:200])
+    bad = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
+    dist.all_reduce(bad)                                                              # over gloo
+    if bad.item() == 0:
+        return "nccl (RCCL, device tensors): " + what, grp
+    sys.stderr.write("bench.py: rank %s: RCCL bring-up failed on %d of %d ranks (%s): bookkeeping stays on gloo\n"
+                     % (os.environ.get("RANK"), int(bad.item()), dist.get_world_size(), err))
+    return "gloo (cpu tensors) after RCCL bring-up failed on %d of %d ranks: %s" % (int(bad.item()), dist.get_world_size(), what), None
 
 
 def spawn_ranks(n):

@@ -49,6 +49,10 @@ def test_bench_line_under_torchrun_with_a_stub_engine(world):
     assert d["extra"]["decoded_bases_total"] == world * steps * rounds * 1100
     h = d["extra"]["host_inclusive"]
     assert h["timed_steps"] == steps and h["kbases_per_s"] > 0
+    # round-5 review item 5: the bookkeeping runs over gloo by default (no RCCL bring-up between a node and its first record) and the
+    # record names every rank's device
+    assert d["config"]["parallelism_bookkeeping"].startswith("gloo (cpu tensors): ")
+    assert d["config"]["devices"] == ["stub:%d" % r for r in range(world)]
 
 
 def _bench(argv, env=None, timeout=600):
@@ -68,6 +72,19 @@ def test_bare_bench_gpus_n_starts_its_own_ranks():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 4 and d["timed_steps"] == 8 and d["extra"]["decoded_bases_total"] == 4 * 8 * 1100
+
+
+def test_backend_nccl_falls_back_to_gloo_when_rccl_does_not_come_up():
+    """`--backend nccl` on a box without a GPU: creating the RCCL group raises on every rank; the ranks agree over the gloo default
+    group, stay on it, and the line says which backend carried the bookkeeping."""
+    out = _bench(["--gpus", "2", "--stub-engine", "8", "--backend", "nccl", "--steps", "3", "--rounds", "1", "--host-rounds", "0", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["extra"]["decoded_bases_total"] == 2 * 3 * 1100
+    assert d["config"]["parallelism_bookkeeping"].startswith("gloo (cpu tensors) after RCCL bring-up failed on 2 of 2 ranks")
+    assert "bookkeeping stays on gloo" in out.stderr
 
 
 def test_bench_refuses_a_launcher_whose_world_size_is_not_gpus():

@@ -1927,13 +1927,18 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     common = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--rounds", "1", "--host-rounds", "0", "--warmup", "1",
               "--no-f16", "--no-cpu-baseline", "--density-rounds", "0"]
-    out = subprocess.run(common + ["--share-gpu", "--backend", "gloo"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(common + ["--share-gpu"], cwd=root, env=env, capture_output=True, text=True, timeout=600)      # bookkeeping: gloo by default
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["timed_steps"] == 4 and d["value"] > 0 and d["data"] == "synthetic"
     assert abs(d["extra"]["windows_per_s"] - 2 * 4 * 1100 / d["timed_region_s"]) / d["extra"]["windows_per_s"] < 0.02     # whole-job aggregate
+    # round-5 review item 5: no RCCL on the way to an N-GPU record, and the record names every rank's device (here: the same GPU twice)
+    cfg = d["config"]
+    assert cfg["parallelism_bookkeeping"].startswith("gloo (cpu tensors): ")
+    assert [v["rank"] for v in cfg["devices"]] == [0, 1] and all(v["hardware"] for v in cfg["devices"])
+    assert cfg["devices"][0]["hardware"] == cfg["devices"][1]["hardware"] and cfg["distinct_devices"] == 1
     import torch
     if torch.cuda.device_count() < 2:
         bad = subprocess.run(common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
