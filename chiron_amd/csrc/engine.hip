@@ -153,6 +153,7 @@ struct ConvGemmPlan {
   // device weights for one fused GEMM
   float* Wt = nullptr;
   float* shift = nullptr;
+  float* descale = nullptr;   // dtype fp32-split: 2^-s[n] of the power-of-two row scaling (GemmParams::descale)
   int N = 0, Npad = 0, K = 0;
 };
 
@@ -352,17 +353,38 @@ static chiron_status upload_gemm(chiron_engine* e, ConvGemmPlan* g, const std::v
   g->K = K;
   chiron_status st;
   if (e->split) {
-    // per 32-element block of a row: 32 hi halves then 32 lo halves (K is a multiple of 32)
+    // per 32-element block of a row: 32 hi halves then 32 lo halves (K is a multiple of 32).  Row n is scaled by 2^s[n] so that its
+    // largest weight lies in [2^12, 2^13): hi <= 8192 is far from a half's 65504, and lo = O(2^-11 w) is a NORMAL half for every
+    // weight down to 2^-15 of the row's largest (GemmParams::descale).  CHIRON_SPLIT_NO_ROW_SCALE=1: the unscaled format of round 5 (A/B).
+    static const bool row_scale = getenv("CHIRON_SPLIT_NO_ROW_SCALE") == nullptr;
     std::vector<_Float16> h(2 * Wt.size());
-    for (size_t i = 0; i < Wt.size(); ++i) {
-      const _Float16 hi = (_Float16)Wt[i];
-      const size_t blk = i / 32, el = i % 32;
-      h[blk * 64 + el] = hi;
-      h[blk * 64 + 32 + el] = (_Float16)(Wt[i] - (float)hi);
+    std::vector<float> sh2(shift), ds((size_t)Npad + 192, 1.0f);
+    for (int n = 0; n < Npad; ++n) {
+      float mx = 0.f;
+      for (int k = 0; k < K; ++k) mx = std::max(mx, fabsf(Wt[(size_t)n * K + k]));
+      int s = 0;
+      if (row_scale && mx > 0.f && std::isfinite(mx)) {
+        int ex;
+        frexpf(mx, &ex);                       // mx = f * 2^ex, 0.5 <= f < 1
+        s = std::min(60, std::max(-60, 13 - ex));
+        if (n < (int)sh2.size() && !std::isfinite(ldexpf(sh2[n], s))) s = 0;
+      }
+      ds[n] = ldexpf(1.0f, -s);
+      if (n < (int)sh2.size()) sh2[n] = ldexpf(sh2[n], s);
+      for (int k = 0; k < K; ++k) {
+        const size_t i = (size_t)n * K + k;
+        const float v = ldexpf(Wt[i], s);
+        const _Float16 hi = (_Float16)v;
+        const size_t blk = i / 32, el = i % 32;
+        h[blk * 64 + el] = hi;
+        h[blk * 64 + 32 + el] = (_Float16)(v - (float)hi);
+      }
     }
     _Float16* d = nullptr;
     if ((st = dev_upload(e, &d, h))) return st;
     g->Wt = reinterpret_cast<float*>(d);
+    if ((st = dev_upload(e, &g->descale, ds))) return st;
+    return dev_upload(e, &g->shift, sh2);
   } else if (e->w2) {
     // every row [K hi halves | K lo halves]: launch() runs the K-segments of a GEMM twice, the second time against the lo columns
     std::vector<_Float16> h(2 * Wt.size());
@@ -1073,6 +1095,7 @@ static void init_gemm(GemmParams* g, const chiron_engine* e, const ConvGemmPlan&
   g->K = w.K;
   g->Wt = w.Wt;
   g->shift = w.shift;
+  g->descale = w.descale;
   g->z_dirs_total = 2;
 }
 

@@ -779,6 +779,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmParams p
       return;
     }
 #endif
+    if constexpr (SPLIT) {
+      // the weight rows (and the shift the accumulators started from) carry a power of two: take it out, exactly (GemmParams::descale)
+      if (p.descale != nullptr) {
+#pragma unroll
+        for (int ni = 0; ni < NNI; ++ni) {
+          if constexpr (ZOUT) {
+            const float ds = p.descale[en0 + ni * 32 + li];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][ni][r] *= ds;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 ds = *reinterpret_cast<const f32x4*>(p.descale + en0 + wn * 64 + ni * 32 + 8 * q + 4 * kh);
+#pragma unroll
+              for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][4 * q + r] *= ds[r];
+            }
+          }
+        }
+      }
+    }
     if constexpr (ZOUT) {
       gemm_epilogue_zrows<NNI>(p, acc, em0, en0, wave, li, kh);
     } else {

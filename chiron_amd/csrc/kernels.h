@@ -68,6 +68,12 @@ struct GemmParams {
   GemmSeg seg[GEMM_MAX_SEG];
   const float* Wt;     // [Npad][K], k contiguous, zero padded; Npad multiple of GEMM_BN
   const float* shift;  // [Npad] added before activation (folded BN offset / LSTM bias), may be null
+  // dtype fp32-split only (nullptr otherwise): row n of Wt and shift[n] are stored multiplied by a power of two 2^s[n] chosen so that
+  // the row's largest weight lies in [2^12, 2^13) -- the `lo` halves of a split weight are then normal halves (a weight of 0.03 has
+  // lo = 1e-5, a SUBNORMAL half: 8 bits instead of 11, and being a constant its error is coherent over all positions; trained-like
+  // weights lost 3 .. 8 x at the logits to that, profiles/r06_split_*) -- and descale[n] = 2^-s[n] is multiplied into the finished
+  // accumulator (exact) before the epilogue.
+  const float* descale;
   int relu;
   // lift (segments with src == nullptr): A = relu(sig[b][in_t]*lift_a[c] + lift_b[c]), 0 outside
   const float* sig;    // [B][L]

@@ -79,7 +79,12 @@ class LocalRanks(object):
                 checked = now
                 if self.parent_pid and not _alive(self.parent_pid):
                     raise RuntimeError("the process that started the ranks (pid %s) is gone: leaving barrier %d" % (self.parent_pid, self.phase))
-                gone = [r for r in self._peers_gone() if "barrier.%d.%d" % (self.phase, r) not in have]
+                gone = self._peers_gone()
+                if gone:
+                    # a peer may have written its marker, passed the barrier and exited (cleanly) between the listing above and the
+                    # kill(pid, 0) probes: list again before calling it dead
+                    have = set(os.listdir(self.folder))
+                    gone = [r for r in gone if "barrier.%d.%d" % (self.phase, r) not in have]
                 if gone:
                     raise RuntimeError("rank(s) %s exited before barrier %d" % (", ".join(map(str, gone)), self.phase))
             if now - t0 > self.timeout_s:
@@ -204,15 +209,33 @@ def spawn_local_ranks(argv, n_gpus, output, python=None, share_gpu=False, grace_
     shutil.rmtree(folder, ignore_errors=True)
     os.makedirs(folder, exist_ok=True)
     procs = []
+    # placement is decided ONCE, here: the GPU -> NUMA node map costs a library load and N PCI lookups, and a rank that pinned itself
+    # after importing the library would leave the threads created during that import on the whole host.  Each child is pinned between
+    # fork and exec, so everything it ever starts inherits its cores; CHIRON_RANK_CPUS records the list (log/engine*.json).
+    try:
+        cpus = [rank_affinity(r, n_gpus, share_gpu) for r in range(n_gpus)]
+    except (AttributeError, OSError):
+        cpus = [None] * n_gpus
+
+    def pin(c):
+        def f():
+            try:
+                os.sched_setaffinity(0, c)
+            except (AttributeError, OSError):
+                pass
+        return f if c else None
+
     for r in range(n_gpus):
         env = dict(os.environ, CHIRON_LOCAL_RANK=str(r), CHIRON_LOCAL_WORLD=str(n_gpus), CHIRON_BARRIER_DIR=folder,
                    CHIRON_PARENT_PID=str(os.getpid()), LOCAL_WORLD_SIZE=str(n_gpus))
+        if cpus[r]:
+            env["CHIRON_RANK_CPUS"] = ",".join(map(str, cpus[r]))
         env.pop("WORLD_SIZE", None)          # the children are not torch.distributed ranks
         pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
         if share_gpu:
             env["CHIRON_SHARE_GPU"] = "1"
-        procs.append(subprocess.Popen([python or sys.executable, "-m", "chiron_amd.entry"] + list(argv), env=env))
+        procs.append(subprocess.Popen([python or sys.executable, "-m", "chiron_amd.entry"] + list(argv), env=env, preexec_fn=pin(cpus[r])))
     codes = [None] * n_gpus
     failed_at = None
     while any(c is None for c in codes):
@@ -232,17 +255,18 @@ def spawn_local_ranks(argv, n_gpus, output, python=None, share_gpu=False, grace_
 
 
 def init_distributed():
-    """One process per GPU under torch.distributed.run: -> (dist or None, rank, world, device or None).  RCCL (backend
-    "nccl") when every rank has its own GPU; with CHIRON_SHARE_GPU=1 -- the self-test of the N > 1 path on a box with
-    one GPU -- all ranks use device 0 and gloo carries the barriers (two RCCL ranks cannot share a device).  Only
-    barriers ever go through it."""
+    """One process per GPU under torch.distributed.run: -> (dist or None, rank, world, device or None).  Only the two barriers
+    of run_sharded ever go through the process group, so it is gloo (north_star: "no RCCL collectives" -- and a sharded call must
+    not depend on RCCL bring-up); CHIRON_DIST_BACKEND=nccl selects RCCL.  With CHIRON_SHARE_GPU=1 -- the self-test of the N > 1
+    path on a box with one GPU -- all ranks use device 0."""
     if os.environ.get("CHIRON_LOCAL_WORLD"):          # a child of `chiron call --gpus N`: file barrier, no torch
         rank, world = int(os.environ["CHIRON_LOCAL_RANK"]), int(os.environ["CHIRON_LOCAL_WORLD"])
         share = os.environ.get("CHIRON_SHARE_GPU") == "1"
-        try:
-            os.sched_setaffinity(0, rank_affinity(rank, world, share))
-        except (AttributeError, OSError):
-            pass
+        if not os.environ.get("CHIRON_RANK_CPUS"):      # started by something other than spawn_local_ranks (which pins before exec)
+            try:
+                os.sched_setaffinity(0, rank_affinity(rank, world, share))
+            except (AttributeError, OSError):
+                pass
         device = 0 if share else rank
         return LocalRanks(rank, world, os.environ["CHIRON_BARRIER_DIR"], parent_pid=os.environ.get("CHIRON_PARENT_PID")), rank, world, device
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -254,7 +278,10 @@ def init_distributed():
     share = os.environ.get("CHIRON_SHARE_GPU") == "1"
     if torch.cuda.is_available() and not share:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("CHIRON_DIST_BACKEND", "gloo") == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
         device = local
     else:
         dist.init_process_group("gloo")

@@ -331,8 +331,8 @@ def cmd_engine(a):
         meta["seconds"]["%s:%d" % (topology, seed)] = round(time.time() - t0, 1)
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    np.savez_compressed(os.path.join(d, "parity_dist_engine.npz"), **out)
-    json.dump(meta, open(os.path.join(d, "parity_dist_engine_meta.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(d, "parity_dist_engine%s.npz" % a.tag), **out)
+    json.dump(meta, open(os.path.join(d, "parity_dist_engine%s_meta.json" % a.tag), "w"), indent=1)
 
 
 # ------------------------------------------------------------------ the judgement
@@ -416,6 +416,7 @@ def main():
     ap.add_argument("--windows", type=int, default=N_WINDOWS)
     ap.add_argument("--dtypes", default="fp32,fp32-split")
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--tag", default="", help="engine: suffix of the output file (A/B runs)")
     a = ap.parse_args()
     a.cases = [(c.split(":")[0], int(c.split(":")[1])) for c in a.cases.split(",")]
     a.dtypes = a.dtypes.split(",")
