@@ -262,6 +262,62 @@ def realisation(spec, w, x, sl, rng):
     return fea, {"plain": nn_oracle.fc_head(h, w32), "peaked": nn_oracle.fc_head(h, wp)}
 
 
+def permute_channels(spec, w, rng):
+    """A function-preserving reparametrisation: every hidden channel axis of the network (the 256 channels behind each convolution,
+    the H units of each LSTM direction) is permuted, producers' outputs and consumers' inputs alike.  Exactly the same function in
+    real arithmetic -- and a DIFFERENT order of every K accumulation for whatever implementation evaluates it, the C oracle's plain
+    sequential loops and the HIP engine's MFMA chains included.  -> weights dict"""
+    sd = spec.to_dict()
+    out = {k: np.array(v) for k, v in w.items()}
+    H = sd["rnn"]["hidden"]
+
+    def conv(site, pin, pout, bn):
+        W = out[site + "/weights"]
+        out[site + "/weights"] = np.ascontiguousarray(W[:, :, pin][:, :, :, pout])
+        if bn:
+            for n in ("scale", "offset", "pop_mean", "pop_var"):
+                out[site + "_bn/" + n] = out[site + "_bn/" + n][pout]
+
+    pin = np.arange(sd["cnn"][0]["in"])
+    for blk in sd["cnn"]:
+        n, c = blk["name"], blk["out"]
+        pa, pb, po = rng.permutation(c), rng.permutation(c), rng.permutation(c)
+        conv(n + "/branch1/conv1", pin, po, blk["i_bn"])
+        conv(n + "/branch2/conv2a", pin, pa, True)
+        conv(n + "/branch2/conv2b", pa, pb, True)
+        conv(n + "/branch2/conv2c", pb, po, True)
+        pin = po
+
+    def cell(prefix, pin_x, pd):
+        k, b = out[prefix + "kernel"], out[prefix + "bias"]
+        nin = k.shape[0] - H
+        rows = np.concatenate([pin_x, nin + pd])
+        cols = np.concatenate([g * H + pd for g in range(4)])
+        out[prefix + "kernel"] = np.ascontiguousarray(k[rows][:, cols])
+        out[prefix + "bias"] = b[cols]
+
+    L = sd["rnn"]["layers"]
+    plast = rng.permutation(H)
+    if sd["rnn"]["kind"] == "stack":
+        px = pin
+        for l in range(L):
+            pf, pbw = (plast, plast) if l == L - 1 else (rng.permutation(H), rng.permutation(H))
+            cell("BDLSTM_rnn/cell_%d/bidirectional_rnn/fw/lstm_cell/" % l, px, pf)
+            cell("BDLSTM_rnn/cell_%d/bidirectional_rnn/bw/lstm_cell/" % l, px, pbw)
+            px = np.concatenate([pf, H + pbw])
+    else:
+        for d in ("fw", "bw"):
+            px = pin
+            for l in range(L):
+                pd_ = plast if l == L - 1 else rng.permutation(H)
+                cell("BDGRU_rnn/%s/multi_rnn_cell/cell_%d/lstm_cell/" % (d, l), px, pd_)
+                px = pd_
+    out["rnn_fnn_layer/weights"] = np.ascontiguousarray(out["rnn_fnn_layer/weights"][:, plast])
+    out["rnn_fnn_layer/bias"] = out["rnn_fnn_layer/bias"][plast]
+    out["rnn_fnn_layer/weights_class"] = np.ascontiguousarray(out["rnn_fnn_layer/weights_class"][plast])
+    return out
+
+
 def fixture_path(topology, seed):
     return os.path.join(FIXTURES, "%s_%d.npz" % (topology, seed))
 
@@ -308,6 +364,55 @@ def cmd_realise(a):
         print("wrote %s (%.0f s)" % (path, time.time() - t0), flush=True)
 
 
+def cmd_chain(a):
+    """`chain` realisations: oracle/chiron_oracle.c -- plain C loops, ONE strictly sequential multiply-then-add chain per output over
+    taps x channels, BN applied to the rounded sum, libm expf / tanhf -- on channel-permuted weights (permute_channels): the most
+    literal float32 reading of the formulas, in a fresh accumulation order per draw.  (C with OpenMP over windows: seconds per draw
+    on a many-core host, which is why these are generated where the cores are: the GPU box's host.)"""
+    from oracle import c_oracle
+    os.makedirs(FIXTURES, exist_ok=True)
+    for topology, seed in a.cases:
+        path = fixture_path(topology, seed).replace(".npz", "_chain.npz")
+        if os.path.exists(path) and not a.force:
+            print("have", path)
+            continue
+        t0 = time.time()
+        spec, L, x, sl, w = case_inputs(topology, seed, a.windows)
+        ref = reference64(spec, w, x, sl)
+        sd, T = spec.to_dict(), spec.output_len(L)
+        acc = {h: {"max": [], "sumsq": []} for h in ("plain", "peaked")}
+        for r in range(a.realisations):
+            rng = np.random.RandomState(200003 * seed + 104729 * r + (0 if topology == "dna" else 1))
+            wp = permute_channels(spec, w, rng)
+            for h, ww in (("plain", wp), ("peaked", peaked(wp))):
+                lg = c_oracle.forward(x, sl, sd, spec.pack(ww), T)
+                mx, sq, cnt = window_stats(lg, ref[h], sl)
+                acc[h]["max"].append(mx)
+                acc[h]["sumsq"].append(sq)
+            print("%s %d chain %d/%d  %.0f s  logits max %.3g rms %.3g" % (topology, seed, r + 1, a.realisations, time.time() - t0,
+                  acc["plain"]["max"][-1].max(), np.sqrt(acc["plain"]["sumsq"][-1].sum() / cnt.sum())), flush=True)
+        out = {"windows": a.windows, "realisations": a.realisations, "count": cnt.astype(np.float32)}
+        for h in acc:
+            out[h + "_max"] = np.asarray(acc[h]["max"], dtype=np.float32)
+            out[h + "_sumsq"] = np.asarray(acc[h]["sumsq"], dtype=np.float32)
+        np.savez_compressed(path, **out)
+        print("wrote %s (%.0f s)" % (path, time.time() - t0), flush=True)
+
+
+def load_ensemble(topology, seed):
+    """the realisations a case is judged against: the blocked-BLAS draws + (when generated) the sequential-chain draws"""
+    fix = dict(np.load(fixture_path(topology, seed)))
+    kinds = ["blocked"] * fix["plain_max"].shape[0]
+    cpath = fixture_path(topology, seed).replace(".npz", "_chain.npz")
+    if os.path.exists(cpath):
+        ch = np.load(cpath)
+        for k in ("plain_max", "plain_sumsq", "peaked_max", "peaked_sumsq"):
+            fix[k] = np.concatenate([fix[k], ch[k]], axis=0)
+        kinds += ["chain"] * ch["plain_max"].shape[0]
+    fix["kinds"] = np.asarray(kinds)
+    return fix
+
+
 # ------------------------------------------------------------------ the engine on the same inputs (GPU)
 def cmd_engine(a):
     import chiron_amd as ca
@@ -327,6 +432,25 @@ def cmd_engine(a):
                 if fea is not None:
                     out["%s_%d_features_rms" % (topology, seed)] = np.sqrt(((fea.astype(np.float64) - ref["features"]) ** 2).mean(axis=(1, 2))).astype(np.float32)
                 print("%s %d %-10s %-6s logits max %.3g rms %.3g" % (topology, seed, dtype, head, mx.max(), np.sqrt(sq.sum() / cnt.sum())), flush=True)
+            # the engine's OWN rounding distribution: the same network with its hidden channels permuted (permute_channels) is the same
+            # function in another accumulation order.  What the draws have in common (their mean error) is the engine's SYSTEMATIC
+            # part -- rounded BN-folded / Winograd-transformed weights, the table, the gate approximations; the rest is accumulation noise
+            if a.engine_draws > 0:
+                dm, dq, esum = [], [], 0.0
+                for r in range(a.engine_draws):
+                    wp = permute_channels(spec, w, np.random.RandomState(300007 * seed + 15485863 * r + (0 if topology == "dna" else 1)))
+                    with ca.Engine(spec, wp, max_batch=x.shape[0], segment_len=L, dtype=dtype) as eng:
+                        lg = eng.infer(x, sl, want_logits=True).logits
+                    mx, sq, cnt = window_stats(lg, ref["plain"], sl)
+                    dm.append(mx)
+                    dq.append(sq)
+                    esum = esum + (lg.astype(np.float64) - ref["plain"])
+                key = "%s_%d_%s_" % (topology, seed, dtype)
+                out[key + "draws_max"], out[key + "draws_sumsq"] = np.asarray(dm, dtype=np.float32), np.asarray(dq, dtype=np.float32)
+                mx, sq, cnt = window_stats(esum / a.engine_draws + ref["plain"], ref["plain"], sl)
+                out[key + "drawmean_max"], out[key + "drawmean_sumsq"] = mx.astype(np.float32), sq.astype(np.float32)
+                print("%s %d %-10s %d permuted draws: set rms %s; rms of their MEAN error %.3g" % (
+                    topology, seed, dtype, a.engine_draws, " ".join("%.3g" % np.sqrt(q.sum() / cnt.sum()) for q in dq), np.sqrt(sq.sum() / cnt.sum())), flush=True)
         out["%s_%d_count" % (topology, seed)] = cnt.astype(np.float32)
         meta["seconds"]["%s:%d" % (topology, seed)] = round(time.time() - t0, 1)
     d = os.path.join(ROOT, "gpurun_out")
@@ -389,7 +513,7 @@ def cmd_judge(a):
     eng = np.load(a.engine_npz)
     rep = {}
     for topology, seed in a.cases:
-        fix = np.load(fixture_path(topology, seed))
+        fix = load_ensemble(topology, seed)
         for dtype in a.dtypes:
             key = "%s_%d_%s_" % (topology, seed, dtype)
             if key + "plain_max" not in eng:
@@ -409,7 +533,8 @@ def cmd_judge(a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=("realise", "engine", "judge"))
+    ap.add_argument("cmd", choices=("realise", "chain", "engine", "judge"))
+    ap.add_argument("--engine-draws", type=int, default=0, help="engine: also run the engine on this many channel-permuted copies of the weights")
     ap.add_argument("engine_npz", nargs="?", default=os.path.join(ROOT, "gpurun_out", "parity_dist_engine.npz"))
     ap.add_argument("--cases", default=",".join("%s:%d" % c for c in CASES))
     ap.add_argument("--realisations", type=int, default=N_REAL)
@@ -420,7 +545,7 @@ def main():
     a = ap.parse_args()
     a.cases = [(c.split(":")[0], int(c.split(":")[1])) for c in a.cases.split(",")]
     a.dtypes = a.dtypes.split(",")
-    {"realise": cmd_realise, "engine": cmd_engine, "judge": cmd_judge}[a.cmd](a)
+    {"realise": cmd_realise, "chain": cmd_chain, "engine": cmd_engine, "judge": cmd_judge}[a.cmd](a)
 
 
 if __name__ == "__main__":
