@@ -423,7 +423,9 @@ def density_region(args, spec, device_id, x_dev, s_dev, xb, lb, step, drain, dec
         e0.infer(x_dev[0], s_dev[0])
         h = e0.rnn_output()[:nfit]
         sl = s_dev[0].cpu().numpy()[:nfit]
-    w = ca.fit_emitting_head(w, h, xb[0][:nfit], sl, BASES_PER_WINDOW, hidden=H)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import regimes                                  # weight regimes of the tests: numpy only, nothing of the oracle
+    w = regimes.fit_emitting_head(w, h, xb[0][:nfit], sl, BASES_PER_WINDOW, hidden=H)
     with ca.Engine(spec, w, max_batch=BATCH, segment_len=SEG_LEN, device_id=device_id, n_slots=args.slots) as ed:
         pending = [None] * args.slots
         for i in range(args.warmup):
@@ -466,7 +468,7 @@ def density_region(args, spec, device_id, x_dev, s_dev, xb, lb, step, drain, dec
             "decoded_bases_per_window": round((decoded_bases[0] - d0) / float(n * BATCH), 2),
             "decoded_bases_per_s": round((decoded_bases[0] - d0) / dt, 1), "consensus_bases_per_s": round((consensus_bases[0] - c0) / dt, 1),
             "half_precision_engines_vs_fp32_greedy_strings": halves,
-            "weights": "the headline's synthetic weights with LSTM forget biases -3 and an FC head fitted (model.fit_emitting_head) on 256 "
+            "weights": "the headline's synthetic weights with LSTM forget biases -3 and an FC head fitted (tests/regimes.py:fit_emitting_head) on 256 "
                        "windows to emit 43.875 bases per window; same step as the headline: submit, collect (SparseTensor D2H), per-read glue vote"}
 
 

@@ -9,6 +9,5 @@ without a GPU raises.
 __version__ = "0.1.0"
 
 from .model import (ModelSpec, dna_default_spec, rna_default_spec, rna_head_spec, synthetic_weights,  # noqa: F401
-                    synthetic_signal, read_config, spec_from_variables, spec_from_config, load_model, fit_emitting_head,
-                    greedy_base_count)
+                    synthetic_signal, read_config, spec_from_variables, spec_from_config, load_model)
 from .engine import Engine, SparseTensor, DecodeResult, seq_len_for_engine  # noqa: F401

@@ -1836,10 +1836,15 @@ extern "C" chiron_status chiron_engine_calibrate(chiron_engine* e, const float* 
   CalibCtx ctx;
   ctx.max_records = 256;
   HIP_TRY(hipMalloc((void**)&ctx.dev_sums, ctx.max_records * 256 * sizeof(double)));
+  struct FreeSums {            // every exit path below, early ones included
+    double* p;
+    ~FreeSums() { (void)hipFree(p); }
+  } free_sums{ctx.dev_sums};
   chiron_status st = CHIRON_OK;
   std::vector<double> sums(ctx.max_records * 256);
   for (int it = 0; it < iterations && st == CHIRON_OK; ++it) {
     ctx.rec.clear();
+    ctx.skipped = 0;
     auto run = [&]() -> chiron_status {
       HIP_TRY(hipMemsetAsync(ctx.dev_sums, 0, ctx.max_records * 256 * sizeof(double), s->stream));
       HIP_TRY(hipMemsetAsync(s->seq, 0, e->BP * 4, s->stream));
@@ -1859,7 +1864,8 @@ extern "C" chiron_status chiron_engine_calibrate(chiron_engine* e, const float* 
     s->net_batch = 0;
     if (st == CHIRON_OK && ctx.skipped)
       st = fail(CHIRON_ERR_OVERFLOW, "calibration could not measure %d of the network's inputs (more than 256 channels, or more than %zu "
-                "measured inputs): no correction applied", ctx.skipped, ctx.max_records);
+                "measured inputs): no correction applied.  Run this model uncorrected (`chiron call --no-calibration`, "
+                "Engine(calibrate=False), `serve.py --no-calibration`) or with dtype fp16-w2, whose weights are exact", ctx.skipped, ctx.max_records);
     if (st) {
       resync_tile_counters(s);
       break;
@@ -1919,7 +1925,6 @@ extern "C" chiron_status chiron_engine_calibrate(chiron_engine* e, const float* 
         st = fail(CHIRON_ERR_DEVICE, "restoring a shift failed");
     e->calibrated = 0;
   }
-  hipFree(ctx.dev_sums);
   return st;
 }
 

@@ -129,7 +129,10 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmParams& p, f32x16 (
             const f32x4 ra4 = *reinterpret_cast<const f32x4*>(p.res_a + n0 + wn * 64 + ni * 32 + 8 * q + 4 * kh);
             const f32x4 rb4 = *reinterpret_cast<const f32x4*>(p.res_b + n0 + wn * 64 + ni * 32 + 8 * q + 4 * kh);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += fmaf(sv, ra4[r], rb4[r]);
+            for (int r = 0; r < 4; ++r) {
+              if (OUTFMT == 1) v[r] = fmaf(sv, ra4[r], v[r]);   // f16 engines: res_b = 0 (shift folded, engine.hip), one fused rounding
+              else v[r] += fmaf(sv, ra4[r], rb4[r]);
+            }
           }
           if (RELU) {
 #pragma unroll

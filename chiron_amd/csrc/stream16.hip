@@ -82,11 +82,9 @@ __global__ __launch_bounds__(64 * S_NW, 1) void conv1x1_f16_stream_kernel(const 
   const int li = lane & 31, kh = lane >> 5;
   __shared__ __attribute__((aligned(16))) float shl[S_C];   // folded BN offset per output column
   __shared__ __attribute__((aligned(16))) float rsl[S_C];   // res_layer1: folded scale of the branch1 convolution of the signal
-  __shared__ __attribute__((aligned(16))) float rbl[S_C];   // ... and its own folded shift (kernels.h res_b)
   if (p.M < 0) tiles[tid] = (_Float16)0.f;   // the tiles are only ever written by the DMA engine (see gemm.hip)
   if (tid < S_C) shl[tid] = p.shift ? p.shift[tid] : 0.f;
   if (tid < S_C) rsl[tid] = p.res_a ? p.res_a[tid] : 0.f;
-  if (tid < S_C) rbl[tid] = (p.res_a && p.res_b) ? p.res_b[tid] : 0.f;
   __syncthreads();
 
   const int ntiles = (p.M + S_ROWS - 1) / S_ROWS;
@@ -134,7 +132,6 @@ __global__ __launch_bounds__(64 * S_NW, 1) void conv1x1_f16_stream_kernel(const 
   // D[i = column][j = row]: lane (row li), registers r -> column 32 w + 8 (r / 4) + 4 kh + r % 4
   const float* const bias = shl + 32 * wave + 4 * kh;   // + 8 q: the four columns of register group q
   const float* const resa = rsl + 32 * wave + 4 * kh;
-  const float* const resb = rbl + 32 * wave + 4 * kh;
   const bool res = p.res_a != nullptr;                  // + sig[b][t * res_stride] * res_a[column] (gemm.hip gemm_epilogue_lean<RES>)
   const float relu_lo = p.relu != 0 ? 0.f : -INFINITY;
   // B operand of k-step ks: logical octet 2 ks + kh of row li, at position (2 ks + kh) ^ (li & 15): one XOR of the lane's base
@@ -204,9 +201,9 @@ __global__ __launch_bounds__(64 * S_NW, 1) void conv1x1_f16_stream_kernel(const 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 r4 = *reinterpret_cast<const f32x4*>(resa + 8 * q);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(resb + 8 * q);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[4 * q + r] += fmaf(sv, r4[r], b4[r]);
+        for (int r = 0; r < 4; ++r) acc[4 * q + r] = fmaf(sv, r4[r], acc[4 * q + r]);   // f16 engines: the branch's shift is folded into
+                                                                                         // the accumulator's start (engine.hip: res_b = 0), ONE fused rounding as in round 4
       }
     }
     char* sw = reinterpret_cast<char*>(stage + (j & 1) * S_STAGE_H) + wr0;

@@ -100,14 +100,81 @@ def peaked_head(w, gain=4.0, blank_bias=2.0):
     return w
 
 
+def greedy_base_count(logits, seq_len):
+    """bases per window of tf.nn.ctc_greedy_decoder (merge_repeated=True, blank = last class; chiron_eval.py:485-487): a frame emits
+    its argmax iff that is not the blank and not the previous frame's argmax.  Counting only -- the decode itself is the engine's."""
+    am = np.argmax(logits, axis=-1)
+    T = am.shape[1]
+    valid = np.arange(T)[None, :] < np.asarray(seq_len)[:, None]
+    prev = np.concatenate([np.full((am.shape[0], 1), -1, dtype=am.dtype), am[:, :-1]], axis=1)
+    return ((am != logits.shape[-1] - 1) & (am != prev) & valid).sum(axis=1)
+
+
+def fit_emitting_head(weights, lasth, x, seq_len, bases_per_window, hidden=100, ridge=1e-3, logit_scale=8.0):
+    """Synthetic weights decode a handful of bases per window; a trained Chiron model emits 16 .. 45 per 400 samples
+    (chiron/example_data/DNA/output/segments) -- 43.9 at 450 bases/s and 4 kHz.  This FITS the FC head
+    (rnn.py:72-96: rnn_fnn_layer/*) of a weight set to emit like one: per-frame targets from the signal (a base where the squiggle
+    jumps by more than four noise sigmas, the base = the quartile of the new level, blank elsewhere; with a strided CNN at most
+    every second frame), a class-balanced ridge regression from `lasth` [B, T, 2H] (the recurrent stack's output on the windows x:
+    chiron_engine_rnn_output, or an oracle's) through the head's own parameterisation with rnn_fnn_layer/weights = 1, logits scaled
+    to `logit_scale` (decided frames are decided by a wide margin, as a trained CTC head's), and the blank bias bisected until the
+    greedy decode of these windows holds `bases_per_window`.  Returns a new weight dict; everything but the four head tensors is
+    shared.  How fast a head CAN switch is the recurrent stack's business: cells that follow their input (forget-gate biases
+    around -2) reach 45 bases per 400 frames, long memories about 25."""
+    h = np.asarray(lasth, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    B, T, _ = h.shape
+    stride = x.shape[1] // T
+    jump = np.abs(np.diff(x, axis=1, prepend=x[:, :1])) > 32.0
+    jump = jump[:, :T * stride].reshape(B, T, stride).any(axis=2)
+    level = x[:, :T * stride].reshape(B, T, stride)[:, :, -1]
+    base = np.searchsorted(np.quantile(level, [0.25, 0.5, 0.75]), level)
+    lab = np.where(jump, base, 4)
+    if stride > 1:
+        lab[:, 1::2] = 4          # a blank between two bases (what CTC needs for a repeat)
+    valid = np.arange(T)[None, :] < np.asarray(seq_len)[:, None]
+    H = hidden
+    pre_all = h[..., :H] + h[..., H:]
+    pre = pre_all[valid]
+    Y = np.eye(5)[lab[valid]]
+    sw = (Y / np.maximum(Y.mean(0), 1e-6)).sum(1)
+    mu = pre.mean(0)
+    pc = pre - mu
+    A = (pc * sw[:, None]).T @ pc
+    A += ridge * np.trace(A) / H * np.eye(H)
+    Wc = np.linalg.solve(A, (pc * sw[:, None]).T @ (Y - Y.mean(0)))
+    gain = logit_scale / max(float(np.abs(pc @ Wc).std()), 1e-9)
+    Wc = (Wc * gain).astype(np.float32)
+    bc0 = Y.mean(0) * gain
+    core = (pre_all - mu).astype(np.float32) @ Wc          # [B, T, 5] without the class bias
+    span = 2.0 * float(np.abs(core).max()) + float(np.abs(bc0).max()) + 1.0
+    lo, hi = -span, span                                  # density falls as the blank bias rises; beyond +-span nothing changes
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        b = bc0.copy()
+        b[4] += mid
+        if greedy_base_count(core + b.astype(np.float32), seq_len).mean() > bases_per_window:
+            lo = mid
+        else:
+            hi = mid
+    b = bc0.copy()
+    b[4] += 0.5 * (lo + hi)
+    out = dict(weights)
+    out["rnn_fnn_layer/weights"] = np.ones((2, H), dtype=np.float32)
+    out["rnn_fnn_layer/bias"] = (-mu).astype(np.float32)
+    out["rnn_fnn_layer/weights_class"] = Wc
+    out["rnn_fnn_layer/bias_class"] = b.astype(np.float32)
+    return out
+
+
 def dense_head(spec, w, x_calib, seq_len, bases_per_window):
     """A trained-CTC-like head that EMITS: most frames blank, a base every few frames -- `bases_per_window` on the calibration
     windows (a trained Chiron model decodes 16 .. 45 bases per 400-sample window: chiron/example_data/DNA/output/segments).
-    ca.fit_emitting_head on the float64 oracle's recurrent output: the class layer is FITTED, the way a trained head is.  Needs
+    fit_emitting_head on the float64 oracle's recurrent output: the class layer is FITTED, the way a trained head is.  Needs
     cells that follow their input: trained_like_weights(forget_mean=-2)."""
     from oracle import nn_oracle
     sd = spec.to_dict()
     w64 = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
     x = np.asarray(x_calib, dtype=np.float64)
     h = nn_oracle.rnn_forward(nn_oracle.cnn_forward(x, sd, w64), seq_len, sd, w64)          # [B, T, 2H]
-    return ca.fit_emitting_head(w, h, x, seq_len, bases_per_window, hidden=spec.hidden)
+    return fit_emitting_head(w, h, x, seq_len, bases_per_window, hidden=spec.hidden)

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import ctc_oracle as co
+import regimes
 
 
 def test_greedy_matches_reference_mapping(golden):
@@ -214,7 +215,7 @@ def test_beam_scores_against_torch_ctc_forward_algorithm(built):
 
 
 def test_greedy_base_count_equals_the_oracle_decode_lengths():
-    """model.greedy_base_count (used by fit_emitting_head to bisect a head's blank bias, and by bench.py's realistic-density leg) counts
+    """regimes.greedy_base_count (used by fit_emitting_head to bisect a head's blank bias, and by bench.py's realistic-density leg) counts
     what tf.nn.ctc_greedy_decoder emits: the oracle's greedy decode, row by row, ragged lengths included."""
     import chiron_amd as ca
     rng = np.random.RandomState(3)
@@ -224,11 +225,11 @@ def test_greedy_base_count_equals_the_oracle_decode_lengths():
         lg[..., 4] += rng.choice([-2.0, 0.0, 3.0])
         sl = rng.randint(0, T + 1, size=B)
         rows, _ = co.greedy_decode(lg, sl)
-        assert ca.greedy_base_count(lg, sl).tolist() == [len(r) for r in rows]
+        assert regimes.greedy_base_count(lg, sl).tolist() == [len(r) for r in rows]
 
 
 def test_fit_emitting_head_reaches_the_requested_density():
-    """model.fit_emitting_head: a recurrent output that encodes the squiggle's level changes (here: planted, plus noise) under the fitted
+    """regimes.fit_emitting_head: a recurrent output that encodes the squiggle's level changes (here: planted, plus noise) under the fitted
     head decodes the requested number of bases per window, on the calibration windows and on held-out ones; only the four head tensors
     of the weight dict change."""
     import chiron_amd as ca
@@ -250,12 +251,12 @@ def test_fit_emitting_head_reaches_the_requested_density():
     w = {"rnn_fnn_layer/weights": np.zeros((2, H), np.float32), "rnn_fnn_layer/bias": np.zeros(H, np.float32),
          "rnn_fnn_layer/weights_class": np.zeros((H, 5), np.float32), "rnn_fnn_layer/bias_class": np.zeros(5, np.float32), "other": np.ones(3)}
     sl = np.full(B, T)
-    out = ca.fit_emitting_head(w, h[:16], x[:16], sl[:16], 12.0, hidden=H)
+    out = regimes.fit_emitting_head(w, h[:16], x[:16], sl[:16], 12.0, hidden=H)
     assert out["other"] is w["other"] and set(out) == set(w)
 
     def density(rows):
         pre = (h[rows, :, :H] * out["rnn_fnn_layer/weights"][0] + h[rows, :, H:] * out["rnn_fnn_layer/weights"][1]) + out["rnn_fnn_layer/bias"]
         lg = pre @ out["rnn_fnn_layer/weights_class"] + out["rnn_fnn_layer/bias_class"]
-        return ca.greedy_base_count(lg, sl[rows]).mean()
+        return regimes.greedy_base_count(lg, sl[rows]).mean()
 
     assert abs(density(slice(0, 16)) - 12.0) < 0.5 and abs(density(slice(16, 24)) - 12.0) < 3.0
