@@ -50,9 +50,22 @@ def ident(a):
     return np.asarray(a, dtype=np.float64)
 
 
+SITES = ("conv2a_1", "conv2b_1", "block_1", "conv2a_2", "conv2b_2", "block_2", "conv2a_3", "conv2b_3", "block_3",
+         "h_1", "h_2", "h_3", "out_1", "out_2", "out_3")
+
+
 def forward(x, sl, spec, w, wq, aq, fold=True, wq_lstm=None, bias_correct=False):
-    """float64 network with weight rounding wq and activation rounding aq; fold: BN scale inside the rounded filter"""
+    """float64 network with weight rounding wq and activation rounding aq; fold: BN scale inside the rounded filter.
+    aq may be a dict {site: rounding} over SITES (a missing site stays wide): conv2a_k / conv2b_k / block_k = the three stored
+    activations of residual block k (block_3 = the CNN features), h_l = the recurrent operand of layer l (what the next step's
+    h @ W_hh reads), out_l = the layer's STORED output (what the next layer's projection, or the FC head, reads)."""
     sd = spec.to_dict()
+    if isinstance(aq, dict):
+        sites = aq
+        aqs = lambda name: sites.get(name, ident)
+    else:
+        one = aq
+        aqs = lambda name: one
     w = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
 
     def conv(xx, site, stride, bn, relu):
@@ -72,13 +85,13 @@ def forward(x, sl, spec, w, wq, aq, fold=True, wq_lstm=None, bias_correct=False)
         return np.maximum(y, 0) if relu else y
 
     a = np.asarray(x, dtype=np.float64)[:, :, None]        # the raw signal: integers below 2048 are exact halves
-    for blk in sd["cnn"]:
+    for bi, blk in enumerate(sd["cnn"], 1):
         n, s = blk["name"], blk.get("stride", 1)
         b1 = conv(a, n + "/branch1/conv1", s, blk["i_bn"], False)
-        c = aq(conv(a, n + "/branch2/conv2a", 1, True, True))
-        c = aq(conv(c, n + "/branch2/conv2b", s, True, True))
+        c = aqs("conv2a_%d" % bi)(conv(a, n + "/branch2/conv2a", 1, True, True))
+        c = aqs("conv2b_%d" % bi)(conv(c, n + "/branch2/conv2b", s, True, True))
         c = conv(c, n + "/branch2/conv2c", 1, True, False)
-        a = aq(np.maximum(b1 + c, 0))                        # the engine adds branch1 inside the conv2c accumulator
+        a = aqs("block_%d" % bi)(np.maximum(b1 + c, 0))      # the engine adds branch1 inside the conv2c accumulator
     H = spec.hidden
     wl = dict(w)
     for k in w:
@@ -92,7 +105,7 @@ def forward(x, sl, spec, w, wq, aq, fold=True, wq_lstm=None, bias_correct=False)
     prev = a
     for layer in range(spec.rnn_layers):
         # h is rounded where it is STORED: the stage's output (read by the next layer and by the recurrence itself)
-        prev = rnn_layer_q(prev, sl, sd, wl, layer, aq, w if bias_correct == 2 else None)
+        prev = rnn_layer_q(prev, sl, sd, wl, layer, (aqs("h_%d" % (layer + 1)), aqs("out_%d" % (layer + 1))), w if bias_correct == 2 else None)
     return nn_oracle.fc_head(prev, wl)
 
 
@@ -123,6 +136,7 @@ def rnn_layer_q(x, sl, sd, w, layer, aq, w_exact=None):
 
 
 def lstm_direction_q(x, seq_len, kernel, bias, reverse, aq):
+    aq_rec, aq_out = aq if isinstance(aq, tuple) else (aq, aq)
     B, T, _ = x.shape
     H = kernel.shape[1] // 4
     out = np.zeros((B, T, H))
@@ -139,11 +153,12 @@ def lstm_direction_q(x, seq_len, kernel, bias, reverse, aq):
         z = np.concatenate([x[rows, t_idx], h], axis=1) @ kernel + bias
         i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
         c_new = sig(f + 1.0) * c + sig(i) * np.tanh(j)
-        h_new = aq(sig(o) * np.tanh(c_new))
+        h_wide = sig(o) * np.tanh(c_new)
+        h_new = aq_rec(h_wide)
         m = active[:, None]
         c = np.where(m, c_new, c)
         h = np.where(m, h_new, h)
-        out[rows[active], t_idx[active]] = h_new[active]
+        out[rows[active], t_idx[active]] = aq_out(h_wide)[active]
     return out
 
 
