@@ -40,23 +40,6 @@ struct __attribute__((aligned(32))) BeamNode {
 // (no libm, no hardware exp2 / log2): the decoder's results are then a pure function of the logits' bits, the same
 // in this kernel, in the sequential kernel below and in the C oracle the tests compare against bit for bit.
 __device__ __forceinline__ float log_sum_exp(float a, float b) { return ctc_log_sum_exp(a, b); }
-// The same function with a WAVE-UNIFORM exact shortcut (round-5 review, item 4).  ctc_log_sum_exp(a, b) = m + ctc_log_pos(1 + e^d),
-// m the larger argument, d <= 0 the difference.  For d < -17 (e^-17 = 4.1e-8 < 2^-24 with a margin far beyond ctc_exp_neg's
-// 1 ulp) the sum 1 + e^d rounds to 1.0f, ctc_log_pos(1.0f) is +0 in every one of its operations, and m + 0 = m: the result IS m,
-// bit for bit -- as it is when either argument is the log of zero.  When every lane that `need`s the value is in that case the
-// 38 instructions of the exp / log pair are skipped by one ballot + branch; otherwise the full function runs for all (a lane
-// cannot skip alone).  CHIRON_BEAM_LSE_SHORTCUT=0 at compile time: the plain function (A/B).
-#ifndef CHIRON_BEAM_LSE_SHORTCUT
-#define CHIRON_BEAM_LSE_SHORTCUT 1
-#endif
-__device__ __forceinline__ float log_sum_exp_wave(float a, float b, bool need) {
-#if CHIRON_BEAM_LSE_SHORTCUT
-  const float m = a > b ? a : b, lo = a > b ? b : a;
-  const bool easy = lo == -INFINITY || lo - m < -17.0f;
-  if (__ballot(need && !easy) == 0ull) return m;
-#endif
-  return ctc_log_sum_exp(a, b);
-}
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -438,16 +421,13 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
         const float p_tot = __shfl(e_tot, src), p_blk = __shfl(e_blk, src);
         const int p_lc = __shfl(e_lc, src);
         float n_label = e_lab;
-        {   // (the two log-sum-exps are evaluated by ALL lanes, outside the branches: their shortcut is decided by a ballot)
-          const bool need1 = e_par >= 0 && pslot != 255;
-          const float ls1 = log_sum_exp_wave(n_label, (e_lc == p_lc) ? p_blk : p_tot, need1);
-          if (need1) n_label = ls1;
-          if (e_par >= 0) n_label += lp_lc;
+        if (e_par >= 0) {
+          if (pslot != 255) n_label = log_sum_exp(n_label, (e_lc == p_lc) ? p_blk : p_tot);
+          n_label += lp_lc;
         }
         const float n_blank = e_tot + lp_blank;
-        const float ls2 = log_sum_exp_wave(n_blank, n_label, inb);
         if (inb) {
-          l_tot = ls2;
+          l_tot = log_sum_exp(n_blank, n_label);
           l_blk = n_blank;
           l_lab = n_label;
 #pragma unroll
@@ -810,16 +790,13 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
         const float p_tot = __shfl(e_tot, src), p_blk = __shfl(e_blk, src);
         const int p_lc = __shfl(e_lc, src);
         float n_label = e_lab;
-        {   // (the two log-sum-exps are evaluated by ALL lanes, outside the branches: their shortcut is decided by a ballot)
-          const bool need1 = e_par >= 0 && pslot != 255;
-          const float ls1 = log_sum_exp_wave(n_label, (e_lc == p_lc) ? p_blk : p_tot, need1);
-          if (need1) n_label = ls1;
-          if (e_par >= 0) n_label += lp_lc;
+        if (e_par >= 0) {
+          if (pslot != 255) n_label = log_sum_exp(n_label, (e_lc == p_lc) ? p_blk : p_tot);
+          n_label += lp_lc;
         }
         const float n_blank = e_tot + lp_blank;
-        const float ls2 = log_sum_exp_wave(n_blank, n_label, inb);
         if (inb) {
-          l_tot = ls2;
+          l_tot = log_sum_exp(n_blank, n_label);
           l_blk = n_blank;
           l_lab = n_label;
 #pragma unroll

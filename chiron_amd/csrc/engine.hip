@@ -19,6 +19,11 @@
 
 #include "../../include/chiron_amd.h"
 #include "kernels.h"
+#include <dlfcn.h>
+
+// profiling buckets (chiron_engine_profile_read) = names of the roctx ranges (CHIRON_ROCTX); order = the PN_* enum below
+static const char* const kProfNames[] = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build",
+                                         "path_prob", "conv_lift", "conv_res", "conv1_pwl", "conv_wino", "lstm_proj0_dma", "conv2a"};
 
 using namespace chiron;
 
@@ -1030,7 +1035,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
     chiron_engine_destroy(e);
     return st;
   }
-  e->prof_names = {"conv_dma", "lstm_proj_dma", "lstm_recurrence", "fc_head", "ctc_greedy", "ctc_beam", "sparse_build", "path_prob", "conv_lift", "conv_res", "conv1_pwl", "conv_wino", "lstm_proj0_dma", "conv2a"};
+  e->prof_names.assign(std::begin(kProfNames), std::end(kProfNames));
   *out = e;
   return CHIRON_OK;
 }
@@ -1066,12 +1071,40 @@ extern "C" chiron_status chiron_engine_dims(const chiron_engine* e, int32_t* out
 // ----------------------------------------------------------------------------------------------
 enum { PN_CONV = 0, PN_PROJ, PN_REC, PN_FC, PN_GREEDY, PN_BEAM, PN_SPARSE, PN_PATHPROB, PN_LIFT, PN_RES, PN_PWL, PN_WINO, PN_PROJ0, PN_CONV2A };
 
+// roctx ranges around every stage's launches (CHIRON_ROCTX=1): a `rocprofv3 --kernel-trace --marker-trace` run then names the stages
+// by themselves -- "conv_wino", "lstm_recurrence", ... -- instead of through bench.py's bucket -> kernel symbol table.  The marker
+// library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so): the engine links only the HIP runtime, and
+// without the switch, or without the library, nothing is called.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* v = getenv("CHIRON_ROCTX");
+    if (!v || !*v || *v == '0') return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) return;
+      push = nullptr, pop = nullptr;
+    }
+    fprintf(stderr, "chiron_amd: CHIRON_ROCTX is set but no roctx library could be loaded: no ranges\n");
+  }
+};
+static const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+
 struct Prof {
   chiron_engine* e;
   Slot* s;
   ProfEvent ev;
   bool on;
-  Prof(chiron_engine* e_, Slot* s_, int name_id, double flops, double bytes) : e(e_), s(s_), on(e_->profiling) {
+  bool range;
+  Prof(chiron_engine* e_, Slot* s_, int name_id, double flops, double bytes) : e(e_), s(s_), on(e_->profiling), range(roctx().push != nullptr) {
+    if (range) roctx().push(kProfNames[name_id]);
     if (!on) return;
     ev.name_id = name_id;
     ev.flops = flops;
@@ -1081,9 +1114,11 @@ struct Prof {
     hipEventRecord(ev.a, s->stream);
   }
   ~Prof() {
-    if (!on) return;
-    hipEventRecord(ev.b, s->stream);
-    s->events.push_back(ev);
+    if (on) {
+      hipEventRecord(ev.b, s->stream);
+      s->events.push_back(ev);
+    }
+    if (range) roctx().pop();
   }
 };
 
