@@ -48,6 +48,7 @@ MODEL_FLOP_PER_WINDOW = 1.451e9                       # reference op count (CNN 
 EXECUTED_FLOP_PER_WINDOW = MODEL_FLOP_PER_WINDOW - SEG_LEN * 2.0 * (1 + 3 * 256) * 256 - 2 * SEG_LEN * 2.0 * 1.5 * 256 * 256
 EXECUTED_SHARE = {"conv_wino": 0.5}                   # MFMA FLOPs a bucket's kernel issues / FLOPs of the op it replaces
 PEAK_F32_MFMA_TFLOPS = 157.3                          # MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+PEAK_F16_MFMA_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: BF16 / FP16 MFMA, dense (32x32x16)
 READ_SAMPLES = 100000                                 # configs[3]: 100k-sample reads -> 257 windows
 
 
@@ -627,8 +628,32 @@ def split_config(spec, weights, x_dev, s_dev, ref32, device_id):
             es.collect(i)
         es.sync()
         dt = time.perf_counter() - t0
+        # its own roofline (round-5 review, item 2): HIP events on the engine's stream, one batch in flight.  Every fp32 product is
+        # three f16 MFMA terms (hi*hi + hi*lo + lo*hi), so a GEMM-shaped bucket EXECUTES 3 x its algorithmic FLOPs on the f16 matrix
+        # pipe (v_mfma_f32_32x32x16_f16 / 16x16x16_f16, dense peak 2500 TFLOP/s); conv2b runs direct here (no Winograd form)
+        es.profile(True)
+        for i in range(3):
+            es.submit(0, x_dev[i % len(x_dev)], s_dev[i % len(s_dev)], beam_width=0, want_prob=True)
+            es.collect(0)
+        stats = es.profile_read()
+        es.profile(False)
+    gemm_like = [k for k in ("lstm_recurrence", "lstm_proj0_dma", "lstm_proj_dma", "conv_dma", "conv2a", "conv_res") if k in stats and stats[k]["total_ms"] > 0]
+    kern = {k: {"ms_per_batch": round(stats[k]["total_ms"] / 3.0, 4), "launches_per_batch": stats[k]["launches"] / 3.0,
+                "algorithmic_tflops": round(stats[k]["flops"] / (stats[k]["total_ms"] * 1e-3) / 1e12, 1),
+                "executed_f16_tflops": round(3.0 * stats[k]["flops"] / (stats[k]["total_ms"] * 1e-3) / 1e12, 1),
+                "frac_of_f16_peak": round(3.0 * stats[k]["flops"] / (stats[k]["total_ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)} for k in gemm_like}
+    dom = max(gemm_like, key=lambda k: stats[k]["total_ms"])
+    tot_ms = sum(v["total_ms"] for v in stats.values()) / 3.0
+    roofline = {"kernel_bucket": dom, "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F16_MFMA_TFLOPS,
+                "achieved": kern[dom]["executed_f16_tflops"], "frac": kern[dom]["frac_of_f16_peak"],
+                "avg_launch_ms": round(stats[dom]["total_ms"] / stats[dom]["launches"], 4),
+                "executed_flops": "3 x the algorithmic FLOPs (three f16 MFMA terms per fp32 product); algorithmic_tflops / 157.3 is the figure comparable with the fp32 engine's roofline",
+                "frac_of_fp32_mfma_peak_in_algorithmic_flops": round(kern[dom]["algorithmic_tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                "mfma_kernels": kern, "single_slot_ms_per_batch": round(tot_ms, 3),
+                "traffic": None, "traffic_note": "no PMC pass for this dtype; profiles/r06_split_kernel_stats.csv holds the rocprofv3 kernel table"}
     return {"workload": "headline workload (batch 1100, greedy), dtype fp32-split",
             "kbases_per_s": round(steps * BATCH * BASES_PER_WINDOW / 1000.0 / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3),
+            "roofline": roofline,
             "logits_vs_f32_engine": {"max_abs": float("%.3e" % d.max()), "mean_abs": float("%.3e" % d.mean()),
                                      "greedy_decode_identical": bool(same), "windows": BATCH}}
 
