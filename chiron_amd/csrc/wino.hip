@@ -25,6 +25,9 @@
 //   ReLU, two 16-byte stores per channel quad.
 // Differs from the direct form by fp32 rounding only (the transforms re-associate the sum over taps).
 #include "kernels.h"
+#ifndef CHIRON_WINO_ROWMAJOR_STORES
+#define CHIRON_WINO_ROWMAJOR_STORES 0   // product form of the F(4,3) epilogue's store order (A/B: tools/variants.sh --product wino CHIRON_WINO_ROWMAJOR_STORES 1)
+#endif
 #include "timing_variants.h"
 
 #include <cstdlib>
@@ -404,6 +407,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
     const int b = qg / qpw, qq = qg - b * qpw;
     float* o0 = p.out + ((long)b * p.T + 4 * qq) * p.ldo + n0 + wn * 32 + 4 * kh;
     const float* sh = shl + n0 + wn * 32 + 4 * kh;
+#if CHIRON_WINO_ROWMAJOR_STORES
+    f32x4 yy[4][4];
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 s4 = *reinterpret_cast<const f32x4*>(sh + 8 * q);
@@ -428,12 +434,24 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
           y3[r] = __builtin_amdgcn_fmed3f(y3[r], 0.f, INFINITY);
         }
       }
+#if CHIRON_WINO_ROWMAJOR_STORES
+      yy[0][q] = y0, yy[1][q] = y1, yy[2][q] = y2, yy[3][q] = y3;
+    }
+    // A/B form (round-5 review, item 7): the four 32-byte pieces that complete one 128-byte line of an output row leave in four
+    // CONSECUTIVE store instructions (row-major) instead of every fourth -- does the L2 merge them better (WRITE_SIZE 553 MB for 450 stored)?
+#pragma unroll
+    for (int row = 0; row < 4; ++row)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(o0 + row * p.ldo + 8 * q) = yy[row][q];
+  };
+#else
       *reinterpret_cast<f32x4*>(o0 + 8 * q) = y0;
       *reinterpret_cast<f32x4*>(o0 + p.ldo + 8 * q) = y1;
       *reinterpret_cast<f32x4*>(o0 + 2 * p.ldo + 8 * q) = y2;
       *reinterpret_cast<f32x4*>(o0 + 3 * p.ldo + 8 * q) = y3;
     }
   };
+#endif
 #if CHIRON_SENS & 2048
   // timing experiment: cycles per tile in the chunk barriers and in the epilogue (s_memtime), printed by wave 0 of four workgroups
   unsigned long long clk_bar = 0, clk_epi = 0, clk_tiles = 0;
