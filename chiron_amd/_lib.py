@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CHIRON_AMD_LIB") or os.path.join(_HERE, "csrc", "libc
 MAX_BLOCKS = 8
 CLASSES = 5
 
-ABI_VERSION = 6      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
+ABI_VERSION = 7      # CHIRON_ABI_VERSION of include/chiron_amd.h this binding was written against
 OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, ERR_OVERFLOW = 0, 1, 2, 3, 4
 RNN_STACK, RNN_MULTI = 0, 1
 BN_POPULATION, BN_BATCH = 0, 1
@@ -56,6 +56,18 @@ class EngineSizes(C.Structure):
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("total_ms", C.c_double), ("launches", C.c_int64),
                 ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class PipelineOpts(C.Structure):
+    _fields_ = [("batch_size", C.c_int32), ("segment_len", C.c_int32), ("jump", C.c_int32), ("start", C.c_int32), ("beam", C.c_int32),
+                ("fastq", C.c_int32), ("concise", C.c_int32), ("rna", C.c_int32), ("no_raw", C.c_int32), ("n_threads", C.c_int32),
+                ("n_slots", C.c_int32), ("null_engine", C.c_int32), ("null_ratio", C.c_double), ("output", C.c_char_p),
+                ("delimiter", C.c_char_p), ("input_name", C.c_char_p), ("model_name", C.c_char_p)]
+
+
+class PipelineStats(C.Structure):
+    _fields_ = [("reads", C.c_int64), ("reads_finished", C.c_int64), ("windows", C.c_int64), ("batches", C.c_int64),
+                ("consensus_bases", C.c_int64), ("files_failed", C.c_int64), ("seconds", C.c_double), ("messages", C.c_char * 4096)]
 
 
 # every symbol include/chiron_amd.h declares: (name, restype, argtypes)
@@ -99,6 +111,7 @@ SYMBOLS = [
     ("chiron_fast5_signal", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
     ("chiron_fast5_fastq", C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]),
     ("chiron_write_signal_text", C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p]),
+    ("chiron_pipeline_run", C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int64, C.POINTER(PipelineOpts), C.POINTER(PipelineStats)]),
     ("chiron_last_error", C.c_char_p, []),
     ("chiron_device_pci_bus_id", C.c_int, [C.c_int32, C.c_char_p, C.c_size_t]),
     ("chiron_abi_version", C.c_int32, []),

@@ -26,7 +26,7 @@
 // Differs from the direct form by fp32 rounding only (the transforms re-associate the sum over taps).
 #include "kernels.h"
 #ifndef CHIRON_WINO_ROWMAJOR_STORES
-#define CHIRON_WINO_ROWMAJOR_STORES 0   // product form of the F(4,3) epilogue's store order (A/B: tools/variants.sh --product wino CHIRON_WINO_ROWMAJOR_STORES 1)
+#define CHIRON_WINO_ROWMAJOR_STORES 1   // store order of the F(4,3) epilogue: 1 = row-major (round 6, WRITE_SIZE 556 -> 453 MB per launch for 450.6 stored, same time: profiles/r06_wino_store_ab.txt); 0 = round 5s (A/B: tools/variants.sh --product wino CHIRON_WINO_ROWMAJOR_STORES 0)
 #endif
 #include "timing_variants.h"
 
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv3_f4_kernel(const WinoParams 
 #if CHIRON_WINO_ROWMAJOR_STORES
       yy[0][q] = y0, yy[1][q] = y1, yy[2][q] = y2, yy[3][q] = y3;
     }
-    // A/B form (round-5 review, item 7): the four 32-byte pieces that complete one 128-byte line of an output row leave in four
+    // (round-5 review, item 7; measured: profiles/r06_wino_store_ab.txt) the four 32-byte pieces that complete one 128-byte line of an output row leave in four
     // CONSECUTIVE store instructions (row-major) instead of every fourth -- does the L2 merge them better (WRITE_SIZE 553 MB for 450 stored)?
 #pragma unroll
     for (int row = 0; row < 4; ++row)

@@ -519,6 +519,46 @@ def _record_engine(FLAGS, engine):
         pass
 
 
+def native_pipeline_ok(FLAGS, engine, fast5_files):
+    """Whether this call can run on chiron_pipeline_run (csrc/pipeline.cpp: the same pipeline with reader / packer / finisher in C++
+    threads, no interpreter lock): the direct fast5 path, a real Engine (or the null engine of the host-ceiling measurement) with
+    population BN, raw DAC counts, names from the file stems, finishers in threads, host vote.  FLAGS.python_pipeline = True (or
+    CHIRON_PYTHON_PIPELINE=1) keeps the Python pools -- the reference implementation the native one is tested against."""
+    if fast5_files is None or getattr(FLAGS, "python_pipeline", False) or os.environ.get("CHIRON_PYTHON_PIPELINE") == "1":
+        return False
+    if getattr(FLAGS, "unit", False) or getattr(FLAGS, "idname", False) or getattr(FLAGS, "python_finish", False):
+        return False
+    if int(getattr(FLAGS, "finish_procs", 0) or 0) > 0:
+        return False
+    if getattr(engine, "null_engine", False):
+        return True
+    return isinstance(engine, Engine) and engine.spec.bn_mode == "population"
+
+
+def run_native_pipeline(FLAGS, engine, fast5_files, n_threads):
+    """chiron_pipeline_run behind evaluation(): -> {read name + ".signal": None} (the consensus strings stay in result/; callers of
+    evaluation() use the keys).  Skipped files are logged the way extract.extract_records logs them."""
+    import ctypes as C
+    from . import _lib
+    from . import extract as extract_mod
+    lib = _lib.load()
+    null = bool(getattr(engine, "null_engine", False))
+    paths = (C.c_char_p * len(fast5_files))(*[os.fsencode(p) for p in fast5_files])
+    opts = _lib.PipelineOpts(FLAGS.batch_size, FLAGS.segment_len, FLAGS.jump, FLAGS.start, FLAGS.beam, int(FLAGS.extension == "fastq"),
+                             int(bool(FLAGS.concise)), int(getattr(FLAGS, "mode", "dna") == "rna"), int(bool(getattr(FLAGS, "no_raw", False))),
+                             n_threads, engine.n_slots, int(null), float(engine.ratio), os.fsencode(FLAGS.output),
+                             getattr(FLAGS, "delimiter", "\n").encode(), str(FLAGS.input).encode(), str(FLAGS.model).encode())
+    stats = _lib.PipelineStats()
+    st = lib.chiron_pipeline_run(None if null else engine._h, paths, len(fast5_files), C.byref(opts), C.byref(stats))
+    for line in stats.messages.decode("utf-8", "replace").splitlines():
+        extract_mod.logger.error(line)
+    if st != _lib.OK:
+        raise _lib.ChironError(st, stats.messages.decode("utf-8", "replace") or lib.chiron_last_error().decode("utf-8", "replace"))
+    names = sorted(n[:-len("." + FLAGS.extension)] for n in os.listdir(os.path.join(FLAGS.output, "result")) if n.endswith("." + FLAGS.extension))
+    evaluation.last_native_stats = {k: getattr(stats, k) for k in ("reads", "reads_finished", "windows", "batches", "consensus_bases", "files_failed", "seconds")}
+    return {n + ".signal": None for n in names}
+
+
 def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
     """chiron_eval.py:378-463 on one GPU.  `file_list` restricts the reads this process handles
     (per-read sharding across GPUs).  `fast5_files` (full paths) switches to the direct fast5 path of
@@ -563,6 +603,13 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
         # thread sits in a 0.4 MB text write), 6 threads 24.2 / 24.5, 12 threads 24.3 / 13.3 (unstable).  -t overrides.
         ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
         n_threads = min(6, max(4, (os.cpu_count() or 16) // (4 * ranks_here)))
+    if native_pipeline_ok(FLAGS, engine, fast5_files):
+        # the whole host side in one native call: C++ reader / finisher threads, this thread packs and talks to the engine (csrc/pipeline.cpp)
+        try:
+            return run_native_pipeline(FLAGS, engine, list(fast5_files), n_threads)
+        finally:
+            if own_engine:
+                engine.close()
     readers = ThreadPoolExecutor(max_workers=n_threads)
     # Finishing (base strings, consensus vote, quality string, three files per read) is Python + numpy + native calls: as
     # threads it is bound by the GIL at a few hundred reads per second, enough for the fp32 engine.  FLAGS.finish_procs > 0

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CHIRON_ABI_VERSION 6
+#define CHIRON_ABI_VERSION 7
 #define CHIRON_MAX_BLOCKS 8
 #define CHIRON_CLASSES 5 /* A,C,G,T,blank (rnn.py:25 class_n=5) */
 
@@ -343,6 +343,37 @@ chiron_status chiron_fast5_fastq(const chiron_fast5* f, int32_t i, char* out, in
 /* extract_sig_ref.py:122-123: delimiter.join(str(v) for v in raw_signal) written to `path` for integer-valued samples
  * (what `chiron call` extracts: unit = False, entry.py:36); a non-integer sample is refused (CHIRON_ERR_INVALID). */
 chiron_status chiron_write_signal_text(const char* path, const float* v, int64_t n, const char* delimiter);
+
+/* The host side of `chiron call` on its direct fast5 path as ONE native call (ABI 7): reader threads (fast5 -> samples, raw/<name>.signal
+ * and reference/<stem>_ref.fastq as extract_sig_ref.py:92-147 writes them, windows as rows of one zero-padded buffer at stride `jump`:
+ * chiron_input.py:276-286), the CALLING thread packing batches across reads in file order (chiron_eval.py:321-334, seq_len rounded half
+ * even :337), submitting them to the engine's slots and regrouping the compact decode per read (:403-446), finisher threads running
+ * chiron_finish_read + meta/<name>.meta (:446-462, :176-242).  It replaces the Python thread pools of chiron_amd/eval.py:evaluation --
+ * same files, byte for byte, except the timings inside meta/ -- for: fast5 input, bn_mode population (a partial last batch is submitted
+ * as it is), host-side vote for every read.  The folders raw/ reference/ result/ segments/ meta/ under `output` must exist.
+ * null_engine != 0: no engine call is made (e may be NULL): collect() is replaced by a canned decode of ~44 bases per window -- the host
+ * pipeline's own ceiling (tools/host_ceiling.py).  Unreadable files are skipped and reported in stats->messages (the reference logs and
+ * skips them, extract_sig_ref.py:97-117); a failed engine call or file write ends the run with its status.                           */
+typedef struct {
+  int32_t batch_size, segment_len, jump, start;   /* FLAGS.batch_size / segment_len / jump / start                                    */
+  int32_t beam;                                    /* 0 = greedy                                                                       */
+  int32_t fastq, concise, rna, no_raw;             /* -e fastq; --concise; --mode rna (signal reversed, U for T); --no-raw             */
+  int32_t n_threads;                               /* reader threads = finisher threads                                                */
+  int32_t n_slots;                                 /* the engine's slots (chiron_engine_opts.n_slots)                                  */
+  int32_t null_engine;
+  double null_ratio;                               /* null engine only: segment_len / T                                                */
+  const char* output;                              /* FLAGS.output                                                                     */
+  const char* delimiter;                           /* of raw/<name>.signal ("\n": HEAD; NULL = "\n")                                   */
+  const char* input_name;                          /* meta/<name>.meta: FLAGS.input, FLAGS.model                                       */
+  const char* model_name;
+} chiron_pipeline_opts;
+typedef struct {
+  int64_t reads, reads_finished, windows, batches, consensus_bases, files_failed;
+  double seconds;
+  char messages[4096];                             /* one line per skipped file / first failure                                        */
+} chiron_pipeline_stats;
+chiron_status chiron_pipeline_run(chiron_engine* e, const char* const* fast5_paths, int64_t n_paths, const chiron_pipeline_opts* opts,
+                                  chiron_pipeline_stats* stats);
 
 /* CRC-32C (Castagnoli) of a byte range: the checksum TF's tensor-bundle checkpoints record per tensor
  * (BundleEntryProto.crc32c holds its masked form; tensor_bundle.cc verifies it in Saver.restore, chiron_eval.py:276).

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == bound, "binding and header disagree: %s" % (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.chiron_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.chiron_abi_version() == _lib.ABI_VERSION == 7
     assert lib.chiron_build_flags() == 0          # the product library is never a timing build
 
 

@@ -1882,6 +1882,41 @@ def test_f32_split_on_raw_signal_extremes(dna, rna, topology):
         assert v["fp32-split"] <= max(TOL, 3.0 * v["fp32"]), (k, v)
 
 
+@pytest.mark.parametrize("beam", [0, 5])
+def test_native_pipeline_equals_the_python_pipeline(dna, tmp_path, beam):
+    """chiron_pipeline_run (csrc/pipeline.cpp: the host side of `chiron call` in C++ threads -- what evaluation() runs on the direct fast5
+    path) against the Python thread pools it replaces, behind the REAL engine: raw/, reference/, result/, segments/ byte for byte and the
+    non-timing lines of meta/, greedy and beam search, reads cut across batches and a partial last batch (population BN: a window's
+    decode does not depend on its batch).  tests/test_pipeline_native.py is the same comparison behind a null engine, on CPU."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_pipeline_native as tp
+    from h5_writer import write_multi_read_fast5
+    from chiron_amd import eval as ce, extract as ex
+    spec, w = dna
+    inp = str(tmp_path / "in")
+    os.makedirs(inp)
+    sig = ca.synthetic_signal(7, 30000, seed=91)
+    for i in range(6):
+        write_multi_read_fast5(os.path.join(inp, "r%02d.fast5" % i), [("", "id-%d" % i, sig[i][:9000 + 4100 * i].astype(np.int16), None)], chunk=8192)
+    write_multi_read_fast5(os.path.join(inp, "r_multi.fast5"), [("read_%d" % k, "m%d" % k, sig[6][k * 9000:(k + 1) * 9000 + 17].astype(np.int16),
+                                                                 "@q\nACGT\n+\n!!!!\n" if k == 0 else None) for k in range(3)])
+    trees = {}
+    with ca.Engine(spec, w, max_batch=300, segment_len=400, n_slots=3, max_beam=beam) as eng:
+        for which in ("python", "native"):
+            F = tp._flags(inp, str(tmp_path / which), python_pipeline=(which == "python"), batch_size=300, beam=beam, model="synthetic")
+            ex.prepare_folders(F)
+            files = ex.list_fast5(inp)
+            assert ce.native_pipeline_ok(F, eng, files) == (which == "native")
+            res = ce.evaluation(F, engine=eng, fast5_files=files)
+            assert len(res) == 9
+            trees[which] = tp._tree(F.output)
+    assert sorted(trees["python"]) == sorted(trees["native"]) and len(trees["native"]) == 9 * 4 + 1
+    for name in trees["python"]:
+        assert trees["python"][name] == trees["native"][name], name
+    assert sum(len(v) for k, v in trees["native"].items() if k.startswith("result/")) > 2000      # the reads decoded to something
+
+
 def test_sharded_call_equals_single_process(tmp_path):
     """BASELINE configs[3] path, scaled to the test box: synthetic 100k-sample reads as .signal files, `chiron call` once
     as one process and once as two ranks under torch.distributed.run (both on GPU 0: CHIRON_SHARE_GPU self-test; per-read

@@ -9,7 +9,7 @@ mkdir -p ../../build
 git show $REV:chiron_amd/csrc/$SRC.hip > ../../build/${SRC}_$REV.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I. -c ../../build/${SRC}_$REV.hip -o ../../build/${SRC}_$REV.o
 objs=""
-for o in engine gemm stream16 stream32 wino lstm head_ctc beam bn_batch pwl consensus assemble fast5; do
+for o in engine gemm stream16 stream32 wino lstm head_ctc beam bn_batch pwl consensus assemble fast5 pipeline; do
   if [ $o = $SRC ]; then objs="$objs ../../build/${SRC}_$REV.o"; else objs="$objs $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/libchiron_${SRC}_$REV.so $objs -lz -ldl

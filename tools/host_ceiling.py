@@ -35,7 +35,10 @@ BASES_PER_WINDOW = 44
 
 
 class NullEngine(object):
-    """The surface of chiron_amd.Engine that eval.evaluation uses, with no device behind it."""
+    """The surface of chiron_amd.Engine that eval.evaluation uses, with no device behind it.  null_engine = True (the default since round
+    6) makes evaluation() run the fast5 path on chiron_pipeline_run (csrc/pipeline.cpp: C++ reader / packer / finisher threads) with ITS
+    null engine -- the same canned ~44 bases per window; HOST_CEILING_PYTHON=1 keeps the Python thread pools (rounds 4 / 5)."""
+    null_engine = os.environ.get("HOST_CEILING_PYTHON") != "1"
 
     def __init__(self, max_batch, segment_len, n_slots=3, engine_ms=0.0, seed=5):
         from chiron_amd.engine import SparseTensor, DecodeResult

@@ -14,7 +14,7 @@ mkdir -p ../../build
 for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $TIMING -D$MACRO=$v -c $SRC.hip -o ../../build/${SRC}_${MACRO}_$v.o
   objs=""
-  for o in engine gemm stream16 stream32 wino lstm head_ctc beam bn_batch pwl consensus assemble fast5; do
+  for o in engine gemm stream16 stream32 wino lstm head_ctc beam bn_batch pwl consensus assemble fast5 pipeline; do
     if [ $o = $SRC ]; then objs="$objs ../../build/${SRC}_${MACRO}_$v.o"; else objs="$objs $o.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/libchiron_${SRC}_${MACRO}_$v.so $objs -lz -ldl
