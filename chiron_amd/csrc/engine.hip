@@ -277,7 +277,8 @@ struct Slot {
   // what chiron_engine_features / chiron_engine_rnn_output may hand out: the batch size of the last NETWORK batch of this slot
   // (0 after a decode-only batch or a failed submit: `batch` alone also counts chiron_engine_decode, which runs no network)
   int net_batch = 0;
-  const float* rnn_out = nullptr;   // the last layer's lasth (time-major [T][BP][lasth_ld]; halves in an f16 engine)
+  const float* rnn_out = nullptr;   // the last layer's lasth (time-major [T][BP][lasth_ld]; rnn_out_f32 = false: halves)
+  bool rnn_out_f32 = true;
   std::vector<ProfEvent> events;
 };
 
@@ -299,6 +300,8 @@ struct chiron_engine {
   bool f16 = false;    // opts.dtype == CHIRON_F16: halves for activations / weights, fp32 accumulate, z, gates, logits
   bool w2 = false;     // opts.dtype == CHIRON_F16_W2: an f16 engine (f16 is set too) whose weights are exact hi + lo half pairs -- every GEMM
                        // runs its K-segments twice ([x, x] . [W_hi; W_lo], tiled DMA GEMMs only), z stays fp32, the recurrence is lstm16w2_kernel
+  bool lasth32 = true;    // f16 engines: the LAST recurrent layer writes its output (what the FC head reads) as fp32 (LstmParams::out_f32);
+                          // CHIRON_F16_LASTH16=1: halves as rounds 2 .. 5 (A/B)
   bool w2_zf16 = false;   // f16-w2, A/B switch CHIRON_W2_ZF16=1: z as halves between projection and recurrence
   bool split = false;  // opts.dtype == CHIRON_F32_SPLIT: fp32 values as hi/lo half pairs on the f16 matrix cores (GEMMs only)
   int lasth_ld = 0;    // elements per lasth row (2H; split: rounded up to whole 32-element blocks)
@@ -985,6 +988,7 @@ extern "C" chiron_status chiron_engine_create(const chiron_model_desc* desc, con
   e->BP = roundup(opts->max_batch, 16);
   e->w2 = opts->dtype == CHIRON_F16_W2;
   e->w2_zf16 = e->w2 && getenv("CHIRON_W2_ZF16") != nullptr;
+  e->lasth32 = getenv("CHIRON_F16_LASTH16") == nullptr;
   e->f16 = opts->dtype == CHIRON_F16 || e->w2;
   e->split = opts->dtype == CHIRON_F32_SPLIT;
   e->kq = e->f16 ? 2 * GEMM_BK : GEMM_BK;
@@ -1410,6 +1414,7 @@ static bool run_cnn(chiron_engine* e, Slot* s, int B, const float* sig) {
 
 static bool run_rnn(chiron_engine* e, Slot* s, int B) {
   bool ok = true;
+  bool last_out_f32 = false;
   const float* fea = s->sig_used;
   const int T = e->T, H = e->H, BP = e->BP;
   const int zc = 4 * H;
@@ -1474,6 +1479,9 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
     }
     r.seq_len = s->seq;
     r.out = e->split ? s->lasth_f32 : outbuf;
+    // f16 engines: the last layer's output goes to the FC head as fp32 (not while the calibration pass measures the layers' outputs as halves)
+    r.out_f32 = (e->f16 && e->lasth32 && e->calib == nullptr && l + 1 == e->lstm.size()) ? 1 : 0;
+    last_out_f32 = r.out_f32 != 0;
     // fp32-split with its own recurrence (lstm32s_kernel): a layer that feeds another projection writes the hi / lo format that
     // projection reads straight into the layer's lasth buffer -- no fp32 copy, no conversion pass; the last layer writes fp32 for the FC head
     const bool direct_split = e->split && lp.wsplit != nullptr && l + 1 < e->lstm.size();
@@ -1534,9 +1542,10 @@ static bool run_rnn(chiron_engine* e, Slot* s, int B) {
   f.BP = BP;
   f.H = H;
   f.K = e->K;
-  f.f16 = e->f16 ? 1 : 0;
+  f.f16 = (e->f16 && !last_out_f32) ? 1 : 0;
   f.split = 0;
   f.ld = e->lasth_ld;
+  s->rnn_out_f32 = !e->f16 || last_out_f32;
   {
     Prof pr(e, s, PN_FC, 2.0 * B * T * (2.0 * H + (double)H * e->K), 4.0 * B * T * (2.0 * H + e->K));
     launch_fc(f, s->stream);
@@ -1982,7 +1991,7 @@ extern "C" chiron_status chiron_engine_rnn_output(chiron_engine* e, int32_t slot
   HIP_TRY(hipSetDevice(e->opts.device_id));
   HIP_TRY(hipStreamSynchronize(s->stream));
   const size_t all = (size_t)T * BP * ld;
-  if (e->f16) {
+  if (!s->rnn_out_f32) {
     std::vector<_Float16> h(all);
     HIP_TRY(hipMemcpy(h.data(), s->rnn_out, all * 2, hipMemcpyDeviceToHost));
     for (int t = 0; t < T; ++t)

@@ -154,6 +154,9 @@ struct LstmParams {
                          //   entry m = 4q + a, lane = kg*16 + gate*4 + j  ->  W_hh[k = 16q + 4kg + a][gate*H + 96 + j]
   const float* wwide32;  // fp32 wide form (lstm32w_kernel): [ndir][8 waves][4 tile slots][25 k-steps][64 lanes], lane = kq*16 + 4u + gate ->
                          //   W_hh[k = 4 ks + kq][gate*H + 4 tile + u], tile = 3 wave + slot (zero for the slots a wave does not use)
+  int out_f32;           // f16 engines, LAST layer (round 6): the layer's output -- what the FC head reads -- is written as fp32, from the cell's
+                         //   own fp32 h, instead of as halves (the recurrent operand h stays a half).  tools/f16_sites.py: under a head with
+                         //   weights of order 100 this ONE rounding flips more windows than all other activation roundings together
   const void* wsplit;    // dtype fp32-split (lstm32s_kernel): W_hh as hi + lo half pairs, [hi | lo] x the order of `wwide`; nullptr: the fp32 kernels
   void* out_split;       // lstm32s_kernel: when set, the output goes HERE in the split hi / lo format the next layer's projection reads
                          //   ([T * BP rows][split_ld], per 32-element block 32 hi halves then 32 lo halves) instead of fp32 to `out`

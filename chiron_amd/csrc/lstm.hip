@@ -413,7 +413,8 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
     if (live) {
       hbuf[(cur ^ 1) * HG16 + hw] = (_Float16)hprev;
       const unsigned to = (dir == 0 || !act) ? s : lenr - 1 - s;
-      outh[to * ostep + olane] = (_Float16)(act ? hnew : 0.f);
+      if (p.out_f32) p.out[to * ostep + olane] = act ? hnew : 0.f;
+        else outh[to * ostep + olane] = (_Float16)(act ? hnew : 0.f);
     }
     cur ^= 1;
     __syncthreads();
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(64 * LSTM_NW, 4) void lstm16_kernel(const LstmParam
     for (int i = tid; i < 4 * p.H; i += 64 * LSTM_NW) {
       const int r = i / p.H;
       const int u = i - r * p.H;
-      outh[((long)s * p.BP + g0 * 4 + r) * outw + dir * p.H + u] = (_Float16)0.f;
+      if (p.out_f32) p.out[((long)s * p.BP + g0 * 4 + r) * outw + dir * p.H + u] = 0.f; else outh[((long)s * p.BP + g0 * 4 + r) * outw + dir * p.H + u] = (_Float16)0.f;
     }
 }
 
@@ -684,7 +685,8 @@ __global__ __launch_bounds__(64 * W16_NW, 2) void lstm16w_kernel(const LstmParam
         c[n] = act ? cn : c[n];
         hprev[n] = act ? hnew : hprev[n];
         hbuf[(cur ^ 1) * HW16 + hw + 64 * n] = (_Float16)hprev[n];
-        outh[to * ostep + olane + 4 * n] = (_Float16)(act ? hnew : 0.f);
+        if (p.out_f32) p.out[to * ostep + olane + 4 * n] = act ? hnew : 0.f;
+        else outh[to * ostep + olane + 4 * n] = (_Float16)(act ? hnew : 0.f);
       }
     }
     cur ^= 1;
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(64 * W16_NW, 2) void lstm16w_kernel(const LstmParam
     for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
       const int r = i / p.H;
       const int uu = i - r * p.H;
-      outh[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
+      if (p.out_f32) p.out[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = 0.f; else outh[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
     }
 }
 
@@ -972,7 +974,8 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16w2_kernel(const LstmPara
         c[n] = act ? cn : c[n];
         hprev[n] = act ? hnew : hprev[n];
         hbuf[(cur ^ 1) * HW16 + hw + 64 * n] = (_Float16)hprev[n];
-        outh[to * ostep + olane + 4 * n] = (_Float16)(act ? hnew : 0.f);
+        if (p.out_f32) p.out[to * ostep + olane + 4 * n] = act ? hnew : 0.f;
+        else outh[to * ostep + olane + 4 * n] = (_Float16)(act ? hnew : 0.f);
       }
     }
     cur ^= 1;
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16w2_kernel(const LstmPara
     for (int i = tid; i < 16 * p.H; i += 64 * W16_NW) {
       const int r = i / p.H;
       const int uu = i - r * p.H;
-      outh[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
+      if (p.out_f32) p.out[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = 0.f; else outh[((long)s * p.BP + g16 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
     }
 }
 
@@ -1019,7 +1022,7 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, _Flo
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
 }
 // CHIRON_F16F_VARIANT (timing_variants.h): instrumented builds of this kernel, 0 in the product
-template <int KSX, int NG>
+template <int KSX, int NG, bool OUT32 = false>
 __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParams p) {
   // NG = 2: one workgroup carries TWO 16-row groups through the same weight registers (every weight fragment feeds two
   // MFMAs): B = 4096 is then exactly one workgroup per CU, and a wave has two independent chains per step to hide the
@@ -1027,6 +1030,9 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
   constexpr int XQ = KSX * 4;                       // k octets (8 halves) of the x tile: KSX k-steps of 32
   constexpr int NTR = NG == 2 ? 3 : 4;              // column-tile slots whose W_x lives in registers (NG = 2: wave 7's fourth in LDS)
   __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * NG * HF16];
+  // OUT32 (the last layer, LstmParams::out_f32): the cells' fp32 h next to its half, same [octet][row][8] positions -- the flush copies
+  // 16-byte pieces (4 units) of THIS tile to an fp32 output instead of 8-byte pieces of the h tile
+  __shared__ __attribute__((aligned(16))) float hout32[OUT32 ? 2 * NG * HF16 : 4];
   _Float16* const xbuf = lstm16f_xtiles();   // [3][NG][XQ octets][16 rows][8 halves]: three deep, the pieces of step s + 2 fly while s is consumed
   __shared__ __attribute__((aligned(16))) f32x4 biasq[W16_NW * W16_NT * 4];             // [wave][tile slot][unit of the tile] -> (i, j, f, o)
   __shared__ __attribute__((aligned(16))) _Float16 wx3[NG == 2 ? KSX * 64 * 8 : 8];   // wave 7, tile slot 3: W_x fragments
@@ -1147,9 +1153,15 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
       for (int k = 0; k < NG; ++k) {
         const bool act = sp < f_len[k];
         const unsigned to = (dir == 0 || !act) ? sp : f_len[k] - 1 - sp;
-        u32x2v v = *reinterpret_cast<const u32x2v*>(hbuf + buf * NG * HF16 + f_lds[k]);
-        if (!act) v = (u32x2v){0u, 0u};
-        *reinterpret_cast<u32x2v*>(outh + (to * ostep + f_out[k])) = v;
+        if (OUT32) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(hout32 + buf * NG * HF16 + f_lds[k]);
+          if (!act) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(p.out + (to * ostep + f_out[k])) = v;
+        } else {
+          u32x2v v = *reinterpret_cast<const u32x2v*>(hbuf + buf * NG * HF16 + f_lds[k]);
+          if (!act) v = (u32x2v){0u, 0u};
+          *reinterpret_cast<u32x2v*>(outh + (to * ostep + f_out[k])) = v;
+        }
       }
     }
   };
@@ -1289,6 +1301,7 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
           c[g][n] = cn;
 #if !(CHIRON_F16F_VARIANT & 64)
           hbuf[((cur ^ 1) * NG + g) * HF16 + h_pos(n)] = (_Float16)hnew;
+          if (OUT32) hout32[((cur ^ 1) * NG + g) * HF16 + h_pos(n)] = hnew;
 #else
           c[g][n] += hnew;
 #endif
@@ -1306,7 +1319,8 @@ __global__ __launch_bounds__(64 * W16_NW, 1) void lstm16f_kernel(const LstmParam
     for (int i = tid; i < 16 * NG * p.H; i += 64 * W16_NW) {
       const int r = i / p.H;
       const int uu = i - r * p.H;
-      outh[((long)s * p.BP + g0 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
+      if (OUT32) p.out[((long)s * p.BP + g0 * 16 + r) * outw + dir * p.H + uu] = 0.f;
+      else outh[((long)s * p.BP + g0 * 16 + r) * outw + dir * p.H + uu] = (_Float16)0.f;
     }
 }
 
@@ -1659,16 +1673,34 @@ void launch_lstm(const LstmParams& p0, hipStream_t stream) {
   if (p.f16 && p.xsrc) {   // fused with the x-projection: the engine asks for it only when whole 16-row groups cover the batch
     // two 16-row groups per workgroup when the padded batch is whole 32-row pairs (4096: one workgroup per CU)
     const int g16 = p.BP / 16;
+    const dim3 blk(64 * W16_NW);
+    if (p.out_f32) {   // the OUT32 forms hold 58 KB of static LDS next to 25 .. 49 KB of dynamic x tiles: ask for the dynamic part explicitly, once
+      static const bool attr_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16f_kernel<8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 32 * 128 * 2 + 16) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16f_kernel<7, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 28 * 128 * 2 + 16) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16f_kernel<8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 128 * 2 + 16) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(lstm16f_kernel<7, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 28 * 128 * 2 + 16) == hipSuccess;
+      }();
+      (void)attr_ok;
+    }
     if (g16 % 2 == 0 && p.fused_pair) {
-      if (p.xK > 224)
-        hipLaunchKernelGGL((lstm16f_kernel<8, 2>), dim3((g16 / 2) * p.ndir), dim3(64 * W16_NW), 3 * 2 * 32 * 128 * 2 + 16, stream, p);
-      else
-        hipLaunchKernelGGL((lstm16f_kernel<7, 2>), dim3((g16 / 2) * p.ndir), dim3(64 * W16_NW), 3 * 2 * 28 * 128 * 2 + 16, stream, p);
+      const dim3 grd((g16 / 2) * p.ndir);
+      if (p.xK > 224) {
+        if (p.out_f32) hipLaunchKernelGGL((lstm16f_kernel<8, 2, true>), grd, blk, 3 * 2 * 32 * 128 * 2 + 16, stream, p);
+        else hipLaunchKernelGGL((lstm16f_kernel<8, 2>), grd, blk, 3 * 2 * 32 * 128 * 2 + 16, stream, p);
+      } else {
+        if (p.out_f32) hipLaunchKernelGGL((lstm16f_kernel<7, 2, true>), grd, blk, 3 * 2 * 28 * 128 * 2 + 16, stream, p);
+        else hipLaunchKernelGGL((lstm16f_kernel<7, 2>), grd, blk, 3 * 2 * 28 * 128 * 2 + 16, stream, p);
+      }
     } else {
-      if (p.xK > 224)
-        hipLaunchKernelGGL((lstm16f_kernel<8, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 3 * 32 * 128 * 2 + 16, stream, p);
-      else
-        hipLaunchKernelGGL((lstm16f_kernel<7, 1>), dim3(g16 * p.ndir), dim3(64 * W16_NW), 3 * 28 * 128 * 2 + 16, stream, p);
+      const dim3 grd(g16 * p.ndir);
+      if (p.xK > 224) {
+        if (p.out_f32) hipLaunchKernelGGL((lstm16f_kernel<8, 1, true>), grd, blk, 3 * 32 * 128 * 2 + 16, stream, p);
+        else hipLaunchKernelGGL((lstm16f_kernel<8, 1>), grd, blk, 3 * 32 * 128 * 2 + 16, stream, p);
+      } else {
+        if (p.out_f32) hipLaunchKernelGGL((lstm16f_kernel<7, 1, true>), grd, blk, 3 * 28 * 128 * 2 + 16, stream, p);
+        else hipLaunchKernelGGL((lstm16f_kernel<7, 1>), grd, blk, 3 * 28 * 128 * 2 + 16, stream, p);
+      }
     }
     return;
   }

@@ -65,6 +65,16 @@ bash tools/pmc_beam.sh "$OUT/pmc_beam" >> "$OUT/${R}_beam_kernel.txt" 2>> "$OUT/
 # 6. fp16 engine at configs[4], kernel trace
 bash tools/f16_profile.sh > "$OUT/f16_kernels.txt" 2> "$OUT/f16_kernels.err"
 
+# 7. dtype fp32-split (round 6): its kernel table with ONE batch in flight (the bench line's extra.f32_split_dtype.roofline uses HIP events;
+#    this is the rocprofv3 view of the same launches) -- the split kernels are the MODE 2 instances of gemm_f32_dma_kernel and lstm32s_kernel
+BENCH_SLOTS=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/split" -o split -- python tools/bench_configs.py split > "$OUT/split_bench.jsonl" 2> "$OUT/split.err"
+find "$OUT/split" -name '*kernel_stats.csv' -exec cp {} "$OUT/${R}_split_kernel_stats_slots1.csv" \;
+
+# 8. roctx ranges (CHIRON_ROCTX=1): the stages named by the engine itself in a marker trace next to the kernel trace
+CHIRON_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d "$OUT/roctx" -o roctx -- \
+  python bench.py --slots 1 --steps 3 --rounds 1 --host-rounds 0 --warmup 1 --no-f16 --density-rounds 0 --no-cpu-baseline > "$OUT/roctx_bench.json" 2> "$OUT/roctx.err"
+find "$OUT/roctx" -name '*marker_api_stats.csv' -exec cp {} "$OUT/${R}_roctx_marker_stats.csv" \;
+
 for i in 1 2 3; do python -c "
 import json,sys
 j=json.loads(open('$OUT/bench_default_$i.json').read().strip().splitlines()[-1]); r=j['roofline']
