@@ -488,7 +488,7 @@ def calibration(r_max, r_sumsq, count, inflate=2.0):
     return null, alt
 
 
-BAR_S1, BAR_RATIO = 0.08, 1.5      # see judge(): every leave-one-out draw passes, doubled draws fail
+BAR_S1, BAR_RATIO, BAR_S2 = 0.15, 1.5, 0.90      # every leave-one-out draw of every case passes S1 and ratio, every doubled draw fails one of them (judge prints both)
 
 
 def judge_case(fix, e_max, e_sumsq):
@@ -500,7 +500,7 @@ def judge_case(fix, e_max, e_sumsq):
         for name, draws in (("leave_one_out", null), ("doubled", alt)):
             st[name] = {k: [float(np.quantile([d[k] for d in draws], q)) for q in (0.0, 0.5, 0.9, 1.0)]
                         for k in ("exceeds_p99_frac", "set_rms_percentile", "median_window_ratio_to_realisations_median")}
-        st["passes"] = bool(st["exceeds_p99_frac"] <= BAR_S1 and st["median_window_ratio_to_realisations_median"] <= BAR_RATIO)
+        st["passes"] = bool(st["exceeds_p99_frac"] <= BAR_S1 and st["median_window_ratio_to_realisations_median"] <= BAR_RATIO and st["set_rms_percentile"] <= BAR_S2)
         st["doubled_draws_rejected_frac"] = float(np.mean([not (d["exceeds_p99_frac"] <= BAR_S1 and d["median_window_ratio_to_realisations_median"] <= BAR_RATIO)
                                                            for d in alt]))
         st["leave_one_out_draws_passing_frac"] = float(np.mean([(d["exceeds_p99_frac"] <= BAR_S1 and d["median_window_ratio_to_realisations_median"] <= BAR_RATIO)
