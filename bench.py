@@ -403,6 +403,15 @@ def main():
         out["extra"]["config5_f16"] = f16_config(spec, weights, x_dev, s_dev, ref32, local_rank)
         out["extra"]["config5_f16_w2"] = f16_config(spec, weights, x_dev, s_dev, ref32, local_rank, dtype="fp16-w2")
         out["extra"]["f32_split_dtype"] = split_config(spec, weights, x_dev, s_dev, ref32, local_rank)
+        # BASELINE configs[4]'s tolerance check where it means something (round-5 review, item 3): windows whose greedy string equals the fp32
+        # engine's, next to the flat-weights logits_vs_f32 above -- measured in this run at a trained model's decode density, and the
+        # committed frontier of every half-precision mode in three regimes (tools/f16_frontier.py)
+        dens = (out["extra"].get("realistic_density") or {}).get("half_precision_engines_vs_fp32_greedy_strings") or {}
+        for key, mode in (("config5_f16", "fp16"), ("config5_f16_w2", "fp16_w2")):
+            out["extra"][key]["identical_windows_vs_f32_engine"] = {
+                "density_regime_this_run": (dens.get(mode) or {}).get("identical_windows_frac"),
+                "bases_per_window": dens.get("bases_per_window_fp32"), "windows": dens.get("windows"),
+                "frontier": frontier_record()}
     if world > 1:
         dist.barrier(group=grp)
         dist.destroy_process_group()
@@ -656,6 +665,18 @@ def split_config(spec, weights, x_dev, s_dev, ref32, device_id):
             "roofline": roofline,
             "logits_vs_f32_engine": {"max_abs": float("%.3e" % d.max()), "mean_abs": float("%.3e" % d.mean()),
                                      "greedy_decode_identical": bool(same), "windows": BATCH}}
+
+
+def frontier_record():
+    """profiles/r06_f16_frontier.json (tools/f16_frontier.py on the GPU box): per regime and mode the identical-window fraction, and the
+    time per 4096 windows -- a static record of an earlier run, named as such"""
+    path = os.path.join(ROOT, "profiles", "r06_f16_frontier.json")
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    return {"source": "static profiles/r06_f16_frontier.json (not this run)", "ms_per_4096_windows": doc.get("ms_per_4096_windows"),
+            "identical_windows_frac": {reg: {m: v["identical_windows_frac"] for m, v in rec["modes"].items()} for reg, rec in doc.get("regimes", {}).items()}}
 
 
 def kernel_sources_digest():
