@@ -460,21 +460,47 @@ def cmd_engine(a):
 
 
 # ------------------------------------------------------------------ the judgement
+TRIM = 3      # windows dropped from the top of every implementation's own squared errors before its set rms is taken
+
+
+def trimmed_rms(sumsq, count, k=TRIM):
+    """rms over the set without the implementation's own k worst windows: one ill-conditioned window (error 100 .. 1000 x the typical
+    window's, for EVERY float32 implementation) otherwise IS the set rms -- 96 % of it on DNA set 7"""
+    o = np.sort(np.asarray(sumsq, dtype=np.float64), axis=-1)
+    return np.sqrt(o[..., :o.shape[-1] - k].sum(axis=-1) / count.sum())
+
+
 def statistics(e_max, e_sumsq, r_max, r_sumsq, count):
     """e_*: [N] of the implementation under test; r_*: [R, N] of the realisations it is judged against"""
-    p99 = np.quantile(r_max, 0.99, axis=0)
     valid = count > 0
-    s1 = float((e_max[valid] > p99[valid]).mean())
+    p99 = np.quantile(r_max, 0.99, axis=0)
+    med = np.median(r_max, axis=0)
+    top = r_max.max(axis=0)
     set_rms = np.sqrt(r_sumsq.sum(axis=1) / count.sum())
     e_rms = float(np.sqrt(e_sumsq.sum() / count.sum()))
-    s2 = float((set_rms < e_rms).mean())
-    # the typical window: median over windows of (error / the realisations' median error for that window)
-    med = np.median(r_max, axis=0)
-    ratio = float(np.median(e_max[valid] / np.maximum(med[valid], 1e-30)))
-    return {"exceeds_p99_frac": s1, "set_rms_percentile": s2, "set_rms": e_rms, "set_max": float(e_max.max()),
-            "median_window_ratio_to_realisations_median": ratio,
+    r_trim, e_trim = trimmed_rms(r_sumsq, count), float(trimmed_rms(e_sumsq, count))
+    return {"exceeds_p99_frac": float((e_max[valid] > p99[valid]).mean()),
+            "median_window_ratio_to_realisations_median": float(np.median(e_max[valid] / np.maximum(med[valid], 1e-30))),
+            "trimmed_rms": e_trim, "trimmed_rms_over_p90": float(e_trim / np.quantile(r_trim, 0.9)), "trimmed_rms_percentile": float((r_trim < e_trim).mean()),
+            "worst_ratio_to_realisations_max": float((e_max[valid] / np.maximum(top[valid], 1e-30)).max()),
+            "set_rms": e_rms, "set_rms_percentile": float((set_rms < e_rms).mean()), "set_max": float(e_max.max()),
+            "realisations_trimmed_rms_p50_p90_max": [float(np.quantile(r_trim, q)) for q in (0.5, 0.9, 1.0)],
             "realisations_set_rms_p50_p90_max": [float(np.quantile(set_rms, q)) for q in (0.5, 0.9, 1.0)],
             "realisations_set_max_p50_p90_max": [float(np.quantile(r_max.max(axis=1), q)) for q in (0.5, 0.9, 1.0)]}
+
+
+# The bars (fp32 engine).  Calibrated on the ensembles themselves (judge_case: leave-one-out draws = the null, the same draws with their
+# error doubled = the alternative); `judge` prints, per case, how many null draws pass and how many doubled draws are rejected.
+BARS = {"trimmed_rms_over_p90": 1.25,                          # bulk: set rms without the implementation's own 3 worst windows <= 1.25 x the ensemble's p90
+        "median_window_ratio_to_realisations_median": 1.5,      # typical window: median over windows of error / the ensemble's median error there
+        "exceeds_p99_frac": 0.15,                               # tail: windows above the ensemble's p99 for that window
+        "worst_ratio_to_realisations_max": 3.0}                 # no window further out than 3 x the ensemble's worst draw there
+# dtype fp32-split carries 22-bit operands (hi + lo halves): held to wider bars, and reported against the fp32 bars as well
+BARS_SPLIT = {"trimmed_rms_over_p90": 1.5, "median_window_ratio_to_realisations_median": 1.75, "exceeds_p99_frac": 0.25, "worst_ratio_to_realisations_max": 3.0}
+
+
+def passes(st, bars=BARS):
+    return all(st[k] <= v for k, v in bars.items())
 
 
 def calibration(r_max, r_sumsq, count, inflate=2.0):
@@ -488,23 +514,24 @@ def calibration(r_max, r_sumsq, count, inflate=2.0):
     return null, alt
 
 
-BAR_S1, BAR_RATIO, BAR_S2 = 0.15, 1.5, 0.90      # every leave-one-out draw of every case passes S1 and ratio, every doubled draw fails one of them (judge prints both)
-
-
-def judge_case(fix, e_max, e_sumsq):
+def judge_case(fix, e_max, e_sumsq, bars=BARS):
     out = {}
+    keys = tuple(BARS) + ("set_rms_percentile", "trimmed_rms_percentile")
     for head in ("plain", "peaked"):
         r_max, r_sumsq, count = fix[head + "_max"].astype(np.float64), fix[head + "_sumsq"].astype(np.float64), fix["count"].astype(np.float64)
         st = statistics(e_max[head].astype(np.float64), e_sumsq[head].astype(np.float64), r_max, r_sumsq, count)
         null, alt = calibration(r_max, r_sumsq, count)
         for name, draws in (("leave_one_out", null), ("doubled", alt)):
-            st[name] = {k: [float(np.quantile([d[k] for d in draws], q)) for q in (0.0, 0.5, 0.9, 1.0)]
-                        for k in ("exceeds_p99_frac", "set_rms_percentile", "median_window_ratio_to_realisations_median")}
-        st["passes"] = bool(st["exceeds_p99_frac"] <= BAR_S1 and st["median_window_ratio_to_realisations_median"] <= BAR_RATIO and st["set_rms_percentile"] <= BAR_S2)
-        st["doubled_draws_rejected_frac"] = float(np.mean([not (d["exceeds_p99_frac"] <= BAR_S1 and d["median_window_ratio_to_realisations_median"] <= BAR_RATIO)
-                                                           for d in alt]))
-        st["leave_one_out_draws_passing_frac"] = float(np.mean([(d["exceeds_p99_frac"] <= BAR_S1 and d["median_window_ratio_to_realisations_median"] <= BAR_RATIO)
-                                                                for d in null]))
+            st[name] = {k: [float(np.quantile([d[k] for d in draws], q)) for q in (0.0, 0.5, 0.9, 1.0)] for k in keys}
+        st["bars"] = dict(bars)
+        st["passes"] = bool(passes(st, bars))
+        st["passes_fp32_bars"] = bool(passes(st, BARS))
+        st["leave_one_out_draws_passing_frac"] = float(np.mean([passes(d, BARS) for d in null]))
+        st["doubled_draws_rejected_frac"] = float(np.mean([not passes(d, BARS) for d in alt]))
+        if "kinds" in fix:
+            kinds = np.asarray(fix["kinds"])
+            st["doubled_draws_rejected_frac_by_kind"] = {k: float(np.mean([not passes(d, BARS) for d, kk in zip(alt, kinds) if kk == k])) for k in sorted(set(kinds.tolist()))}
+            st["leave_one_out_draws_passing_frac_by_kind"] = {k: float(np.mean([passes(d, BARS) for d, kk in zip(null, kinds) if kk == k])) for k in sorted(set(kinds.tolist()))}
         out[head] = st
     return out
 
@@ -519,15 +546,16 @@ def cmd_judge(a):
             if key + "plain_max" not in eng:
                 continue
             rep["%s:%d:%s" % (topology, seed, dtype)] = judge_case(
-                fix, {h: eng[key + h + "_max"] for h in ("plain", "peaked")}, {h: eng[key + h + "_sumsq"] for h in ("plain", "peaked")})
+                fix, {h: eng[key + h + "_max"] for h in ("plain", "peaked")}, {h: eng[key + h + "_sumsq"] for h in ("plain", "peaked")},
+                BARS if dtype == "fp32" else BARS_SPLIT)
     path = os.path.join(ROOT, "gpurun_out", "parity_dist_report.json")
     json.dump(rep, open(path, "w"), indent=1, sort_keys=True)
     for k, v in rep.items():
         for h, st in v.items():
-            print("%-22s %-6s S1 %.3f (LOO max %.3f, doubled min %.3f)  S2 %.2f  typical-window ratio %.2f (LOO max %.2f)  set rms %.3g max %.3g  %s" % (
-                k, h, st["exceeds_p99_frac"], st["leave_one_out"]["exceeds_p99_frac"][3], st["doubled"]["exceeds_p99_frac"][0], st["set_rms_percentile"],
-                st["median_window_ratio_to_realisations_median"], st["leave_one_out"]["median_window_ratio_to_realisations_median"][3],
-                st["set_rms"], st["set_max"], "PASS" if st["passes"] else "FAIL"))
+            print("%-20s %-6s bulk %.2f x p90 (pct %.2f) | typical %.2f | tail %.3f | worst %.2f x max | null passing %.2f, doubled rejected %.2f | set rms %.3g (pct %.2f) max %.3g  %s" % (
+                k, h, st["trimmed_rms_over_p90"], st["trimmed_rms_percentile"], st["median_window_ratio_to_realisations_median"], st["exceeds_p99_frac"],
+                st["worst_ratio_to_realisations_max"], st["leave_one_out_draws_passing_frac"], st["doubled_draws_rejected_frac"], st["set_rms"],
+                st["set_rms_percentile"], st["set_max"], "PASS" if st["passes"] else "FAIL"))
     print("wrote", path)
 
 
