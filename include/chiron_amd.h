@@ -98,12 +98,18 @@ chiron_status chiron_weights_size(const chiron_model_desc* desc, size_t* n_float
 /* CHIRON_F32: exact-fp32 path (fp32 MFMA), the parity path: logits within 1e-4 of the reference arithmetic.
  * CHIRON_F16: activations, weights and the recurrent h as IEEE halves on the f16 MFMA instructions; accumulation,
  *             the LSTM pre-activations z, gates, cell state, logits and both CTC decoders stay fp32 (BASELINE
- *             configs[4]).  Logits stay within 0.08 of the fp32 engine (tests/test_gpu_parity.py).
- * CHIRON_F32_SPLIT: fp32 VALUES, carried between kernels as exact hi + lo half pairs (x = hi + lo to 2^-22) and
- *             multiplied on the f16 matrix cores as hi*hi + hi*lo + lo*hi with fp32 accumulation (the f16 MFMA rate is
- *             16x the fp32 one on gfx950); recurrence, gates, z, logits and CTC are the fp32 code.  Opt-in: it meets the
- *             same 1e-4 logits bound against the oracle as CHIRON_F32 (tests) but it is not bit-for-bit fp32 MFMA
- *             arithmetic, so the headline benchmark stays on CHIRON_F32.  Population BN only.
+ *             configs[4]); the LAST recurrent layer's output -- what the FC head reads -- leaves the recurrence as fp32 (round 6).
+ *             Logits stay within 0.08 of the fp32 engine on the synthetic weights (tests/test_gpu_parity.py); identical-window rates
+ *             against the fp32 engine per regime: profiles/r06_f16_frontier.json.
+ * CHIRON_F32_SPLIT: fp32 VALUES, carried between kernels as hi + lo half pairs (x = hi + lo to 2^-22: 22-bit operands) and multiplied
+ *             on the f16 matrix cores as hi*hi + hi*lo + lo*hi with fp32 accumulation (the f16 MFMA rate is 16x the fp32 one on
+ *             gfx950); GEMM weight rows are stored scaled by a power of two so that their lo halves are normal halves; gates, z, logits
+ *             and CTC are the fp32 code.  Opt-in.  What it meets (tests): the 1e-4 logits bound against the oracle on the seeded
+ *             synthetic weights, as CHIRON_F32 does; on trained-checkpoint-like weights, where no float32 pipeline meets 1e-4, it is
+ *             judged against the same ensemble of float32 realisations as CHIRON_F32 with wider bars (bulk rms <= 1.5 x the ensemble's
+ *             p90, typical window <= 1.75 x its median; measured 0.75 .. 1.4 and 1.0 .. 1.6 -- CHIRON_F32: 0.65 .. 1.15 and 1.2 .. 1.45);
+ *             greedy strings at basecalling density as CHIRON_F32.  It is not fp32 MFMA arithmetic, so the headline benchmark stays
+ *             on CHIRON_F32.  Population BN only.
  * CHIRON_F16_W2: CHIRON_F16's activations (halves) against EXACT weights: every weight is carried as a hi + lo half pair
  *             (W = hi + lo to 2^-22) and every product is x*lo + x*hi on the f16 matrix cores, fp32 accumulation; the LSTM
  *             pre-activations z stay fp32 in memory.  What half precision costs this network is mostly the WEIGHTS'
