@@ -106,6 +106,8 @@ def main():
                          "on CPU tensors: the N-GPU record does not depend on RCCL bring-up.  'nccl' (= RCCL) stays selectable; when "
                          "its initialisation raises, the ranks fall back to gloo together and config.parallelism_bookkeeping says so")
     ap.add_argument("--share-gpu", action="store_true", help="self-test only: every rank uses GPU 0")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic in THIS run")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: three single-slot batches and exit (the workload of the --pmc child runs)")
     ap.add_argument("--no-f16", action="store_true", help="skip the extra measurements (configs[4]: fp16 batch 4096; fp32-split dtype)")
     ap.add_argument("--stub-engine", type=float, default=0.0, metavar="MS",
                     help="self-test of the multi-rank bookkeeping WITHOUT a GPU (tests/test_bench_ranks.py): the engine is replaced "
@@ -113,6 +115,8 @@ def main():
                          "gloo: there is no RCCL without a GPU).  Never a measurement: the "
                          "line says data = 'stub'.")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child()
     stub = args.stub_engine > 0
     if stub:
         args.no_f16, args.no_cpu_baseline, args.density_rounds = True, True, 0
@@ -328,7 +332,16 @@ def main():
         dom = stats[dom_key]
         dom_symbol = BUCKET_SYMBOL[dom_key]
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom_symbol)
+        traffic, traffic_src = pmc_traffic(dom_symbol)          # the committed record (also feeds the per-kernel pmc blocks below)
+        live = None if (args.no_live_pmc or world != 1) else live_pmc_traffic()
+        if live and live.get("kernels"):
+            rec = next((v for k, v in live["kernels"].items() if dom_symbol in k), None)
+            if rec and rec.get("hbm_bytes"):
+                static_traffic, static_src = traffic, traffic_src
+                traffic = rec["hbm_bytes"]
+                traffic_src = ("measured in THIS run: two child processes of this script under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
+                               "(separate passes, %d / %d launches, three single-slot batches each); committed record for comparison: %s (%s)"
+                               % (rec["launches_fetch"], rec["launches_write"], static_traffic, static_src))
         per_bucket = {k: {"symbol": BUCKET_SYMBOL[k], "ms_per_batch": round(stats[k]["total_ms"] / 3.0, 4),
                           "launches_per_batch": stats[k]["launches"] / 3.0,
                           "achieved": round(EXECUTED_SHARE.get(k, 1.0) * stats[k]["flops"] / (stats[k]["total_ms"] * 1e-3) / 1e12, 2),
@@ -353,7 +366,9 @@ def main():
                     "lstm_gemm_roofline_frac_whole_path": round(windows / dt * LSTM_GEMM_FLOP_PER_WINDOW / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4),
                     "lstm_gemm_flop_per_window": LSTM_GEMM_FLOP_PER_WINDOW,
                     "mfma_kernels": per_bucket,
-                    "traffic_source": traffic_src}
+                    "traffic_source": traffic_src,
+                    "traffic_live": None if not live else {"error": live.get("error"), "seconds": live.get("seconds"),
+                                                            "hbm_bytes_per_launch": {k: v.get("hbm_bytes") for k, v in (live.get("kernels") or {}).items()}}}
         # north_star: "rocprof HBM GB/s on the conv and MFMA utilisation on the LSTM": the PMC pass's counters next to this
         # run's launch times (HBM GB/s = PMC bytes per launch / HIP-event launch time); absent when the PMC record is stale
         for k in mfma_buckets:
@@ -665,6 +680,63 @@ def split_config(spec, weights, x_dev, s_dev, ref32, device_id):
             "roofline": roofline,
             "logits_vs_f32_engine": {"max_abs": float("%.3e" % d.max()), "mean_abs": float("%.3e" % d.mean()),
                                      "greedy_decode_identical": bool(same), "windows": BATCH}}
+
+
+def pmc_child():
+    """--pmc-child: the workload of the live PMC passes -- the headline engine, ONE slot, three batches of the headline workload from host
+    buffers, no timing, no torch.  rocprofv3 wraps this process; the parent parses its counter_collection.csv."""
+    import chiron_amd as ca
+    spec = ca.dna_default_spec()
+    xb, lb, _, _ = make_batches(1, 0)
+    with ca.Engine(spec, ca.synthetic_weights(spec, seed=1234), max_batch=BATCH, segment_len=SEG_LEN, n_slots=1) as eng:
+        sl = ca.seq_len_for_engine(lb[0], eng.ratio)
+        for _ in range(3):
+            eng.submit(0, xb[0], sl, beam_width=0, want_prob=True)
+            eng.collect(0)
+    return 0
+
+
+def live_pmc_traffic():
+    """HBM bytes per launch of every kernel of the path, measured in THIS run (round-5 review, Weak #6: the line used to carry the
+    builder's committed record): this script as a child process under `rocprofv3 --kernel-trace --pmc <counter>`, once for FETCH_SIZE
+    and once for WRITE_SIZE (separate passes, kernel trace only -- MI355X_MICROARCH.md's recipe), from /tmp.  hbm_bytes =
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (the guide's gfx950 correction of FETCH_SIZE).  -> {"kernels": {name: {...}}, ...} or
+    {"error": ...}: a box without rocprofv3, a failing child or an unreadable csv leave the committed record in place."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    t0 = time.perf_counter()
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not found"}
+    acc = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="chiron_pmc_", dir="/tmp")
+            try:
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=240)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    return {"error": "rocprofv3 --pmc %s: rc %d, %d csv files: %s" % (counter, r.returncode, len(files), (r.stderr or "")[-300:]), "seconds": round(time.perf_counter() - t0, 1)}
+                for path in files:
+                    for row in csv.DictReader(open(path)):
+                        if row.get("Counter_Name") == counter:
+                            name = row.get("Kernel_Name", "").replace("void ", "").replace("chiron::", "").split("(")[0]
+                            acc.setdefault(name, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+        return {"error": "%s: %s" % (type(e).__name__, e), "seconds": round(time.perf_counter() - t0, 1)}
+    kernels = {}
+    for name, c in acc.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f, w = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]), sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+            kernels[name] = {"hbm_bytes": (2.0 * f + w) * 1024.0, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                             "launches_fetch": len(c["FETCH_SIZE"]), "launches_write": len(c["WRITE_SIZE"])}
+    return {"kernels": kernels, "seconds": round(time.perf_counter() - t0, 1), "error": None if kernels else "no kernel carried both counters"}
 
 
 def frontier_record():
