@@ -121,6 +121,7 @@ extern "C" chiron_status chiron_pipeline_run(chiron_engine* e, const char* const
   std::condition_variable lcv;
   std::atomic<int64_t> next_file{0};
   int64_t consumed = 0;            // under lm
+  int64_t ahead_windows = 0;       // under lm: windows of the files loaded and not yet consumed
   std::atomic<bool> stop{false};
   auto load = [&](int64_t fi) {
     Loaded& out = loaded[(size_t)fi];
@@ -198,13 +199,16 @@ extern "C" chiron_status chiron_pipeline_run(chiron_engine* e, const char* const
         if (fi >= n_paths) return;
         {
           std::unique_lock<std::mutex> lk(lm);
-          lcv.wait(lk, [&] { return stop.load() || fi < consumed + 2 * n_threads; });
+          // read-ahead: 2 * n_threads files as the Python pools -- or, when that is less than three batches' worth of windows (batch 4096
+          // of 257-window reads takes 16 files per batch: twelve files ahead starve the engine), until three batches are waiting
+          lcv.wait(lk, [&] { return stop.load() || fi < consumed + 2 * n_threads || (ahead_windows < 3 * (int64_t)B && fi < consumed + 4096); });
           if (stop.load()) return;
         }
         load(fi);
         {
           std::lock_guard<std::mutex> lk(lm);
           loaded[(size_t)fi].ready = true;
+          for (auto& r : loaded[(size_t)fi].reads) ahead_windows += r->n_win;
         }
         lcv.notify_all();
       }
@@ -359,6 +363,7 @@ extern "C" chiron_status chiron_pipeline_run(chiron_engine* e, const char* const
       std::unique_lock<std::mutex> lk(lm);
       lcv.wait(lk, [&] { return loaded[(size_t)fi].ready; });
       consumed = fi + 1;
+      for (auto& r : loaded[(size_t)fi].reads) ahead_windows -= r->n_win;
     }
     lcv.notify_all();
     Loaded& ld = loaded[(size_t)fi];
