@@ -40,6 +40,12 @@ struct __attribute__((aligned(32))) BeamNode {
 // (no libm, no hardware exp2 / log2): the decoder's results are then a pure function of the logits' bits, the same
 // in this kernel, in the sequential kernel below and in the C oracle the tests compare against bit for bit.
 __device__ __forceinline__ float log_sum_exp(float a, float b) { return ctc_log_sum_exp(a, b); }
+// wave priority of the register kernels (s_setprio): 3 = ahead of the other batches' persistent GEMM waves (the product since round 3);
+// 0 = the round-5 review's "decoder behind the next batch's network" (A/B: tools/variants.sh --product beam CHIRON_BEAM_PRIO 0;
+// profiles/r06_beam_priority_ab.txt)
+#ifndef CHIRON_BEAM_PRIO
+#define CHIRON_BEAM_PRIO 3
+#endif
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(64) void beam64_kernel(const BeamParams p, int node
   // One latency-bound wave per window next to the other batches' GEMM waves: with equal priority a saturated MFMA wave
   // leaves a VALU wave of its SIMD about one issue slot per MFMA (tools/ubench/valu_exec_mask.hip).  Measured same-box
   // with three batches in flight: 11.81 / 11.83 ms per beam-30 batch against 11.87 / 11.95.
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(CHIRON_BEAM_PRIO);
 
   const int W = p.beam;
   const int lane = threadIdx.x;
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(64) void beam32x2_kernel(const BeamParams p, int no
   __shared__ unsigned csu[64];
   __shared__ unsigned csr[64];
   __shared__ unsigned char rmap[64];
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(CHIRON_BEAM_PRIO);
 
   const int W = p.beam;
   const int lane = threadIdx.x;

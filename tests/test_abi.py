@@ -60,7 +60,7 @@ def test_timing_variants_cannot_ship_silently(built, tmp_path):
     header = open(os.path.join(csrc, "timing_variants.h")).read()
     declared = set(re.findall(r"#ifndef (CHIRON_[A-Z0-9_]+)", header))
     assert declared == {"CHIRON_SENS", "CHIRON_W32_VARIANT", "CHIRON_F16F_VARIANT", "CHIRON_S16_VARIANT"}
-    product_forms = {"CHIRON_GATE_MATH", "CHIRON_WINO_ROWMAJOR_STORES"}   # compile-time choices that compute correct results (lstm.hip, wino.hip)
+    product_forms = {"CHIRON_GATE_MATH", "CHIRON_WINO_ROWMAJOR_STORES", "CHIRON_BEAM_PRIO"}   # compile-time choices that compute correct results (lstm.hip, wino.hip, beam.hip)
     for name in os.listdir(csrc):
         if name.endswith((".hip", ".cpp", ".h")) and name != "timing_variants.h":
             text = open(os.path.join(csrc, name)).read()
