@@ -696,13 +696,34 @@ def pmc_child():
     return 0
 
 
+def collect_counter(files, counter, acc):
+    """rows of rocprofv3's *counter_collection.csv files -> acc[kernel name without `void`, namespace and argument list][counter] = [values]"""
+    import csv
+    for path in files:
+        for row in csv.DictReader(open(path)):
+            if row.get("Counter_Name") == counter:
+                name = row.get("Kernel_Name", "").replace("void ", "").replace("chiron::", "").split("(")[0]
+                acc.setdefault(name, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+    return acc
+
+
+def hbm_bytes_per_launch(acc):
+    """acc of collect_counter -> {kernel: {hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md's gfx950 correction), ...}}"""
+    kernels = {}
+    for name, c in acc.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f, w = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]), sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+            kernels[name] = {"hbm_bytes": (2.0 * f + w) * 1024.0, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                             "launches_fetch": len(c["FETCH_SIZE"]), "launches_write": len(c["WRITE_SIZE"])}
+    return kernels
+
+
 def live_pmc_traffic():
     """HBM bytes per launch of every kernel of the path, measured in THIS run (round-5 review, Weak #6: the line used to carry the
     builder's committed record): this script as a child process under `rocprofv3 --kernel-trace --pmc <counter>`, once for FETCH_SIZE
     and once for WRITE_SIZE (separate passes, kernel trace only -- MI355X_MICROARCH.md's recipe), from /tmp.  hbm_bytes =
     (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (the guide's gfx950 correction of FETCH_SIZE).  -> {"kernels": {name: {...}}, ...} or
     {"error": ...}: a box without rocprofv3, a failing child or an unreadable csv leave the committed record in place."""
-    import csv
     import glob
     import shutil
     import subprocess
@@ -721,21 +742,12 @@ def live_pmc_traffic():
                 files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
                 if r.returncode != 0 or not files:
                     return {"error": "rocprofv3 --pmc %s: rc %d, %d csv files: %s" % (counter, r.returncode, len(files), (r.stderr or "")[-300:]), "seconds": round(time.perf_counter() - t0, 1)}
-                for path in files:
-                    for row in csv.DictReader(open(path)):
-                        if row.get("Counter_Name") == counter:
-                            name = row.get("Kernel_Name", "").replace("void ", "").replace("chiron::", "").split("(")[0]
-                            acc.setdefault(name, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+                collect_counter(files, counter, acc)
             finally:
                 shutil.rmtree(d, ignore_errors=True)
     except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
         return {"error": "%s: %s" % (type(e).__name__, e), "seconds": round(time.perf_counter() - t0, 1)}
-    kernels = {}
-    for name, c in acc.items():
-        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            f, w = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]), sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
-            kernels[name] = {"hbm_bytes": (2.0 * f + w) * 1024.0, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
-                             "launches_fetch": len(c["FETCH_SIZE"]), "launches_write": len(c["WRITE_SIZE"])}
+    kernels = hbm_bytes_per_launch(acc)
     return {"kernels": kernels, "seconds": round(time.perf_counter() - t0, 1), "error": None if kernels else "no kernel carried both counters"}
 
 

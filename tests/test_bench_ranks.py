@@ -111,3 +111,25 @@ def test_ranks_must_sit_on_distinct_devices():
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300) for p in ps]
     assert [p.returncode for p in ps] == [4, 4] and "share a device" in outs[0][1]
+
+
+def test_live_pmc_counter_files_to_hbm_bytes(tmp_path):
+    """bench.py measures roofline.traffic in the run itself: two child passes under rocprofv3 --pmc write *counter_collection.csv files;
+    this is the parsing half (the GPU half runs with the bench): kernel names lose `void`, the namespace and the argument list, values
+    are averaged per launch, hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, a kernel seen in only one pass is left out."""
+    sys.path.insert(0, ROOT)
+    import bench
+    head = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
+    row = '1,1,1,1,1,1,1,1,"%s",256,0,0,64,16,%s,%s,0,1\n'
+    rd, wr = tmp_path / "a_counter_collection.csv", tmp_path / "b_counter_collection.csv"
+    rd.write_text(head + row % ("chiron::lstm32w2_kernel(chiron::LstmParams)", "FETCH_SIZE", "1000") + row % ("chiron::lstm32w2_kernel(chiron::LstmParams)", "FETCH_SIZE", "3000")
+                  + row % ("void chiron::gemm_f32_dma_kernel<true, false, 8, false, 0, true>(chiron::GemmParams)", "FETCH_SIZE", "10") + row % ("only_read(int)", "FETCH_SIZE", "5"))
+    wr.write_text(head + row % ("chiron::lstm32w2_kernel(chiron::LstmParams)", "WRITE_SIZE", "500")
+                  + row % ("void chiron::gemm_f32_dma_kernel<true, false, 8, false, 0, true>(chiron::GemmParams)", "WRITE_SIZE", "20"))
+    acc = bench.collect_counter([str(rd)], "FETCH_SIZE", {})
+    acc = bench.collect_counter([str(wr)], "WRITE_SIZE", acc)
+    k = bench.hbm_bytes_per_launch(acc)
+    assert set(k) == {"lstm32w2_kernel", "gemm_f32_dma_kernel<true, false, 8, false, 0, true>"}
+    assert k["lstm32w2_kernel"]["hbm_bytes"] == (2 * 2000 + 500) * 1024 and k["lstm32w2_kernel"]["launches_fetch"] == 2
+    assert k["gemm_f32_dma_kernel<true, false, 8, false, 0, true>"]["hbm_bytes"] == (2 * 10 + 20) * 1024
+    assert any(bench.BUCKET_SYMBOL["lstm_proj0_dma"] in name for name in k)       # the bucket -> symbol table finds its kernel by substring
