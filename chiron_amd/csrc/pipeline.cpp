@@ -418,7 +418,19 @@ extern "C" chiron_status chiron_pipeline_run(chiron_engine* e, const char* const
   }
   fcv.notify_all();
   for (auto& t : finishers) t.join();
-  if (status != CHIRON_OK && !o->null_engine) chiron_engine_sync(e);
+  std::string engine_error;
+  if (status != CHIRON_OK && !o->null_engine) {
+    // a failed engine call: keep its reason, then return every slot that still holds a batch to idle (collect drains the slot's stream and
+    // resets its state) -- the caller's engine stays usable
+    engine_error = chiron_last_error();
+    for (int k = 0; k < n_slots; ++k)
+      if (inflight[(size_t)k]) {
+        chiron_decoded d;
+        (void)chiron_engine_collect(e, k, &d);
+        inflight[(size_t)k].reset();
+      }
+    chiron_engine_sync(e);
+  }
   if (st_out) {
     memset(st_out, 0, sizeof *st_out);
     st_out->reads = n_reads;
@@ -431,6 +443,7 @@ extern "C" chiron_status chiron_pipeline_run(chiron_engine* e, const char* const
     std::string all;
     for (auto& m : errors) all += m + "\n";
     if (!first_error.empty()) all += first_error + "\n";
+    if (!engine_error.empty()) all += "engine: " + engine_error + "\n";
     snprintf(st_out->messages, sizeof st_out->messages, "%s", all.c_str());
   }
   if (status == CHIRON_OK && n_failed.load() > 0) return CHIRON_ERR_INVALID;

@@ -1960,6 +1960,35 @@ def test_native_pipeline_equals_the_python_pipeline(dna, tmp_path, beam):
     assert sum(len(v) for k, v in trees["native"].items() if k.startswith("result/")) > 2000      # the reads decoded to something
 
 
+def test_native_pipeline_engine_error_leaves_the_engine_usable(dna, tmp_path):
+    """chiron_pipeline_run with a request the engine refuses (a beam width above the engine's max_beam): the call ends with the engine's
+    status and its reason, no slot is left holding a batch, and the same engine basecalls the same files afterwards."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_pipeline_native as tp
+    from h5_writer import write_multi_read_fast5
+    from chiron_amd import eval as ce, extract as ex
+    spec, w = dna
+    inp = str(tmp_path / "in")
+    os.makedirs(inp)
+    sig = ca.synthetic_signal(3, 20000, seed=93)
+    for i in range(3):
+        write_multi_read_fast5(os.path.join(inp, "r%d.fast5" % i), [("", "id-%d" % i, sig[i].astype(np.int16), None)])
+    with ca.Engine(spec, w, max_batch=64, segment_len=400, n_slots=3, max_beam=0) as eng:
+        F = tp._flags(inp, str(tmp_path / "bad"), batch_size=64, beam=7, model="synthetic")
+        ex.prepare_folders(F)
+        for sub in ("segments", "result", "meta"):
+            os.makedirs(os.path.join(F.output, sub), exist_ok=True)
+        with pytest.raises(_lib.ChironError) as err:
+            ce.run_native_pipeline(F, eng, ex.list_fast5(inp), 2)
+        assert "engine:" in str(err.value)
+        G = tp._flags(inp, str(tmp_path / "good"), batch_size=64, beam=0, model="synthetic")
+        ex.prepare_folders(G)
+        assert len(ce.evaluation(G, engine=eng, fast5_files=ex.list_fast5(inp))) == 3
+        x = np.zeros((5, 400), np.float32)
+        eng.infer(x, np.full(5, 400, np.int32))                      # every slot is idle again
+
+
 def test_sharded_call_equals_single_process(tmp_path):
     """BASELINE configs[3] path, scaled to the test box: synthetic 100k-sample reads as .signal files, `chiron call` once
     as one process and once as two ranks under torch.distributed.run (both on GPU 0: CHIRON_SHARE_GPU self-test; per-read
