@@ -62,7 +62,7 @@ class PipelineOpts(C.Structure):
     _fields_ = [("batch_size", C.c_int32), ("segment_len", C.c_int32), ("jump", C.c_int32), ("start", C.c_int32), ("beam", C.c_int32),
                 ("fastq", C.c_int32), ("concise", C.c_int32), ("rna", C.c_int32), ("no_raw", C.c_int32), ("n_threads", C.c_int32),
                 ("n_slots", C.c_int32), ("null_engine", C.c_int32), ("null_ratio", C.c_double), ("output", C.c_char_p),
-                ("delimiter", C.c_char_p), ("input_name", C.c_char_p), ("model_name", C.c_char_p)]
+                ("delimiter", C.c_char_p), ("input_name", C.c_char_p), ("model_name", C.c_char_p), ("name_root", C.c_char_p)]
 
 
 class PipelineStats(C.Structure):

@@ -30,6 +30,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "../../include/chiron_amd.h"
 
 namespace {
@@ -52,6 +54,7 @@ struct Read {
 struct Loaded {                // one input file, filled by a reader thread
   std::vector<std::shared_ptr<Read>> reads;
   std::vector<std::string> errors;
+  std::string fatal;           // a `.signal` file that cannot be read or parsed ends the run (the reference raises)
   bool ready = false;
 };
 
@@ -87,6 +90,16 @@ std::string stem_of(const std::string& path) {
   std::string base = s == std::string::npos ? path : path.substr(s + 1);
   const size_t d = base.find_last_of('.');
   return d == std::string::npos ? base : base.substr(0, d);
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+void make_parent_dirs(const std::string& path) {      // mkdir -p dirname(path)
+  for (size_t i = 1; i < path.size(); ++i)
+    if (path[i] == '/') mkdir(path.substr(0, i).c_str(), 0777);
 }
 
 std::string fmt(const char* f, double v) {
@@ -127,6 +140,45 @@ extern "C" chiron_status chiron_pipeline_run(chiron_engine* e, const char* const
     Loaded& out = loaded[(size_t)fi];
     const std::string full = paths[fi], stem = stem_of(full);
     double t0 = now_s();
+    if (ends_with(full, ".signal")) {                 // read_signal (chiron_input.py:527-539): whitespace-separated numbers -> float32
+      auto r = std::make_shared<Read>();
+      std::string rel = full;
+      if (o->name_root) {
+        const std::string rootdir = o->name_root;
+        if (rel.compare(0, rootdir.size(), rootdir) == 0) rel = rel.substr(rootdir.size());
+        while (!rel.empty() && rel[0] == '/') rel.erase(0, 1);
+      } else {
+        const size_t sl = rel.find_last_of('/');
+        if (sl != std::string::npos) rel = rel.substr(sl + 1);
+      }
+      r->name = rel.substr(0, rel.size() - 7);
+      std::string text;
+      FILE* fi_ = fopen(full.c_str(), "rb");
+      bool ok = fi_ != nullptr;
+      if (ok) {
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, fi_)) > 0) text.append(chunk, got);
+        ok = ferror(fi_) == 0;
+        fclose(fi_);
+      }
+      std::vector<float> sig(text.size() / 2 + 1);
+      size_t ns = 0;
+      if (!ok) out.fatal = "cannot read " + full;
+      else if (chiron_parse_signal_text(text.data(), text.size(), sig.data(), sig.size(), &ns) != CHIRON_OK) out.fatal = full + ": " + chiron_last_error();
+      if (!out.fatal.empty()) return;
+      r->n = std::max<int64_t>(0, (int64_t)ns - o->start);
+      r->n_win = r->n > 0 ? (int32_t)((r->n + J - 1) / J) : 0;
+      if (r->n_win > 0) {
+        r->buf.assign((size_t)(r->n_win - 1) * J + L, 0.0f);
+        const int64_t m = std::min<int64_t>(r->n, (int64_t)r->buf.size());
+        memcpy(r->buf.data(), sig.data() + o->start, (size_t)m * sizeof(float));
+      }
+      r->t0 = t0;
+      r->t_read = now_s() - t0;
+      out.reads.push_back(std::move(r));
+      return;
+    }
     chiron_fast5* f = nullptr;
     if (chiron_fast5_open(full.c_str(), &f) != CHIRON_OK) {
       out.errors.push_back("Cannot extract file " + full + ". " + chiron_last_error());
@@ -233,6 +285,13 @@ extern "C" chiron_status chiron_pipeline_run(chiron_engine* e, const char* const
     int64_t clen = 0;
     const std::string ext = fastq ? "fastq" : "fasta";
     const std::string res = root + "/result/" + r.name + "." + ext, seg = root + "/segments/" + r.name + "." + ext;
+    if (r.name.find('/') != std::string::npos) {     // a recursive `.signal` input: <sub-folder>/<read> (chiron_eval.py:280-283)
+      make_parent_dirs(res);
+      if (!o->concise) {
+        make_parent_dirs(seg);
+        make_parent_dirs(root + "/meta/" + r.name + ".meta");
+      }
+    }
     const chiron_status s = chiron_finish_read(r.flat.empty() ? &none : r.flat.data(), off.data(), n_seg, qs, kernal, 0.2, (double)J / (double)L, r.name.c_str(),
                                                res.c_str(), o->concise ? nullptr : seg.c_str(), fastq ? 1 : 0, o->rna, nullptr, 0, &clen);
     if (s != CHIRON_OK) {
@@ -368,6 +427,11 @@ extern "C" chiron_status chiron_pipeline_run(chiron_engine* e, const char* const
     lcv.notify_all();
     Loaded& ld = loaded[(size_t)fi];
     for (auto& m : ld.errors) errors.push_back(m);
+    if (!ld.fatal.empty()) {
+      errors.push_back(ld.fatal);
+      status = CHIRON_ERR_INVALID;
+      break;
+    }
     for (auto& rp : ld.reads) {
       ++n_reads;
       if (rp->n_win == 0) {            // nothing behind `start`: an empty consensus, as the reference writes it

@@ -519,23 +519,26 @@ def _record_engine(FLAGS, engine):
         pass
 
 
-def native_pipeline_ok(FLAGS, engine, fast5_files):
+def native_pipeline_ok(FLAGS, engine, fast5_files, signal_names=None):
     """Whether this call can run on chiron_pipeline_run (csrc/pipeline.cpp: the same pipeline with reader / packer / finisher in C++
-    threads, no interpreter lock): the direct fast5 path, a real Engine (or the null engine of the host-ceiling measurement) with
-    population BN, raw DAC counts, names from the file stems, finishers in threads, host vote.  FLAGS.python_pipeline = True (or
+    threads, no interpreter lock): the direct fast5 path (raw DAC counts, names from the file stems) or a folder of `.signal` text files,
+    a real Engine (or the null engine of the host-ceiling measurement) with population BN, finishers in threads, host vote.  FLAGS.python_pipeline = True (or
     CHIRON_PYTHON_PIPELINE=1) keeps the Python pools -- the reference implementation the native one is tested against."""
-    if fast5_files is None or getattr(FLAGS, "python_pipeline", False) or os.environ.get("CHIRON_PYTHON_PIPELINE") == "1":
+    if getattr(FLAGS, "python_pipeline", False) or os.environ.get("CHIRON_PYTHON_PIPELINE") == "1":
         return False
-    if getattr(FLAGS, "unit", False) or getattr(FLAGS, "idname", False) or getattr(FLAGS, "python_finish", False):
+    if fast5_files is None:          # a folder of `.signal` files (what extraction leaves under raw/, or the caller's own): all of them text
+        if not signal_names or not all(n.endswith(".signal") for n in signal_names) or getattr(FLAGS, "reverse_fast5", False):
+            return False
+    elif getattr(FLAGS, "unit", False) or getattr(FLAGS, "idname", False):      # extraction options the native reader does not cover
         return False
-    if int(getattr(FLAGS, "finish_procs", 0) or 0) > 0:
+    if getattr(FLAGS, "python_finish", False) or int(getattr(FLAGS, "finish_procs", 0) or 0) > 0:
         return False
     if getattr(engine, "null_engine", False):
         return True
     return isinstance(engine, Engine) and engine.spec.bn_mode == "population"
 
 
-def run_native_pipeline(FLAGS, engine, fast5_files, n_threads):
+def run_native_pipeline(FLAGS, engine, fast5_files, n_threads, name_root=None):
     """chiron_pipeline_run behind evaluation(): -> {read name + ".signal": None} (the consensus strings stay in result/; callers of
     evaluation() use the keys).  Skipped files are logged the way extract.extract_records logs them."""
     import ctypes as C
@@ -547,14 +550,16 @@ def run_native_pipeline(FLAGS, engine, fast5_files, n_threads):
     opts = _lib.PipelineOpts(FLAGS.batch_size, FLAGS.segment_len, FLAGS.jump, FLAGS.start, FLAGS.beam, int(FLAGS.extension == "fastq"),
                              int(bool(FLAGS.concise)), int(getattr(FLAGS, "mode", "dna") == "rna"), int(bool(getattr(FLAGS, "no_raw", False))),
                              n_threads, engine.n_slots, int(null), float(engine.ratio), os.fsencode(FLAGS.output),
-                             getattr(FLAGS, "delimiter", "\n").encode(), str(FLAGS.input).encode(), str(FLAGS.model).encode())
+                             getattr(FLAGS, "delimiter", "\n").encode(), str(FLAGS.input).encode(), str(FLAGS.model).encode(),
+                             None if name_root is None else os.fsencode(name_root))
     stats = _lib.PipelineStats()
     st = lib.chiron_pipeline_run(None if null else engine._h, paths, len(fast5_files), C.byref(opts), C.byref(stats))
     for line in stats.messages.decode("utf-8", "replace").splitlines():
         extract_mod.logger.error(line)
     if st != _lib.OK:
         raise _lib.ChironError(st, stats.messages.decode("utf-8", "replace") or lib.chiron_last_error().decode("utf-8", "replace"))
-    names = sorted(n[:-len("." + FLAGS.extension)] for n in os.listdir(os.path.join(FLAGS.output, "result")) if n.endswith("." + FLAGS.extension))
+    res_dir, ext = os.path.join(FLAGS.output, "result"), "." + FLAGS.extension
+    names = sorted(os.path.relpath(os.path.join(dp, n), res_dir)[:-len(ext)] for dp, _, fns in os.walk(res_dir) for n in fns if n.endswith(ext))
     evaluation.last_native_stats = {k: getattr(stats, k) for k in ("reads", "reads_finished", "windows", "batches", "consensus_bases", "files_failed", "seconds")}
     return {n + ".signal": None for n in names}
 
@@ -603,10 +608,13 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
         # thread sits in a 0.4 MB text write), 6 threads 24.2 / 24.5, 12 threads 24.3 / 13.3 (unstable).  -t overrides.
         ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
         n_threads = min(6, max(4, (os.cpu_count() or 16) // (4 * ranks_here)))
-    if native_pipeline_ok(FLAGS, engine, fast5_files):
+    signal_names = None if fast5_files is not None else [n for n in files if n.endswith(".signal") or n.endswith(".fast5")]
+    if native_pipeline_ok(FLAGS, engine, fast5_files, signal_names):
         # the whole host side in one native call: C++ reader / finisher threads, this thread packs and talks to the engine (csrc/pipeline.cpp)
         try:
-            return run_native_pipeline(FLAGS, engine, list(fast5_files), n_threads)
+            if fast5_files is not None:
+                return run_native_pipeline(FLAGS, engine, list(fast5_files), n_threads)
+            return run_native_pipeline(FLAGS, engine, [os.path.join(file_dir, n) for n in signal_names], n_threads, name_root=file_dir)
         finally:
             if own_engine:
                 engine.close()

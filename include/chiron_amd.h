@@ -356,7 +356,8 @@ chiron_status chiron_write_signal_text(const char* path, const float* v, int64_t
  * even :337), submitting them to the engine's slots and regrouping the compact decode per read (:403-446), finisher threads running
  * chiron_finish_read + meta/<name>.meta (:446-462, :176-242).  It replaces the Python thread pools of chiron_amd/eval.py:evaluation --
  * same files, byte for byte, except the timings inside meta/ -- for: fast5 input, bn_mode population (a partial last batch is submitted
- * as it is), host-side vote for every read.  The folders raw/ reference/ result/ segments/ meta/ under `output` must exist.
+ * as it is), host-side vote for every read; `.signal` text files are taken as well (name_root).  The folders raw/ reference/ result/
+ * segments/ meta/ under `output` must exist (sub-folders of a recursive `.signal` input are created on demand).
  * null_engine != 0: no engine call is made (e may be NULL): collect() is replaced by a canned decode of ~44 bases per window -- the host
  * pipeline's own ceiling (tools/host_ceiling.py).  Unreadable files are skipped and reported in stats->messages (the reference logs and
  * skips them, extract_sig_ref.py:97-117); a failed engine call or file write ends the run with its status.                           */
@@ -372,6 +373,9 @@ typedef struct {
   const char* delimiter;                           /* of raw/<name>.signal ("\n": HEAD; NULL = "\n")                                   */
   const char* input_name;                          /* meta/<name>.meta: FLAGS.input, FLAGS.model                                       */
   const char* model_name;
+  const char* name_root;                           /* `.signal` inputs (a path ending in ".signal" is parsed as text: chiron_input.py:527-539, and
+                                                      nothing is written to raw/ or reference/): a read is named by its path relative to this
+                                                      folder, sub-folders included (chiron_eval.py:277-293); NULL: by its file name          */
 } chiron_pipeline_opts;
 typedef struct {
   int64_t reads, reads_finished, windows, batches, consensus_bases, files_failed;

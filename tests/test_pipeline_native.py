@@ -82,13 +82,13 @@ def _flags(inp, out, **kw):
 def _tree(root):
     out = {}
     for sub in ("raw", "reference", "result", "segments", "meta"):
-        d = os.path.join(root, sub)
-        for n in sorted(os.listdir(d)) if os.path.isdir(d) else []:
-            data = open(os.path.join(d, n), "rb").read()
-            if sub == "meta":          # timings differ run to run: keep the headers and the two setting lines, and the read length
-                lines = data.decode().split("\n")
-                data = "\n".join([lines[0], lines[2], lines[3], lines[4], lines[5]]).encode()
-            out[sub + "/" + n] = data
+        for dp, _, fns in os.walk(os.path.join(root, sub)):
+            for n in sorted(fns):
+                data = open(os.path.join(dp, n), "rb").read()
+                if sub == "meta":          # timings differ run to run: keep the headers and the two setting lines, and the read length
+                    lines = data.decode().split("\n")
+                    data = "\n".join([lines[0], lines[2], lines[3], lines[4], lines[5]]).encode()
+                out[os.path.relpath(os.path.join(dp, n), root)] = data
     return out
 
 
@@ -115,6 +115,49 @@ def test_native_pipeline_equals_the_python_pipeline_behind_a_null_engine(tmp_pat
     assert st["reads"] == st["reads_finished"] == 12 and st["files_failed"] == 1 and st["windows"] > 0
     log = open(os.path.join(str(tmp_path / "native"), "log", "extract.log")).read()
     assert "c_damaged.fast5" in log and "Cannot extract file" in log
+
+
+@pytest.mark.parametrize("case", [{}, {"extension": "fasta", "batch_size": 9}, {"concise": True, "start": 3}])
+def test_native_pipeline_on_a_folder_of_signal_files(tmp_path, built, case):
+    """the other input of `chiron call`: a (recursive) folder of `.signal` text files -- what extraction leaves under raw/, or the caller's
+    own (chiron_eval.py:277-293, chiron_input.py:527-539): names keep their sub-folder, nothing is written to raw/ or reference/;
+    space- and newline-separated files, a float-valued one (pA), an empty one."""
+    from chiron_amd import fast5
+    inp = tmp_path / "sig"
+    (inp / "sub" / "deeper").mkdir(parents=True)
+    rng = np.random.RandomState(8)
+    fast5.write_signal_text(str(inp / "a.signal"), rng.randint(200, 1000, size=12345).astype(np.float32), "\n")
+    fast5.write_signal_text(str(inp / "sub" / "b.signal"), rng.randint(200, 1000, size=4000).astype(np.float32), " ")
+    fast5.write_signal_text(str(inp / "sub" / "deeper" / "c.signal"), rng.randint(200, 1000, size=801).astype(np.float32), "\n")
+    (inp / "d_float.signal").write_text(" ".join(repr(float(v)) for v in rng.uniform(60.0, 160.0, size=2500)))
+    (inp / "e_empty.signal").write_text("")
+    (inp / "notes.txt").write_text("not a read")
+    trees, results = {}, {}
+    for which in ("python", "native"):
+        F = _flags(str(inp), str(tmp_path / which), python_pipeline=(which == "python"), **case)
+        for sub in ("result", "segments", "meta"):
+            os.makedirs(os.path.join(F.output, sub))
+        eng = CannedEngine(F.batch_size, F.segment_len)
+        results[which] = ce.evaluation(F, engine=eng)
+        trees[which] = _tree(F.output)
+    assert sorted(results["python"]) == sorted(results["native"]) == ["a.signal", "d_float.signal", "e_empty.signal", "sub/b.signal", "sub/deeper/c.signal"]
+    assert ce.evaluation.last_native_stats["reads"] == 5
+    py, nat = trees["python"], trees["native"]
+    assert sorted(py) == sorted(nat) and all(py[k] == nat[k] for k in py), [k for k in py if py.get(k) != nat.get(k)]
+    assert "result/sub/deeper/c." + case.get("extension", "fastq") in nat
+
+
+def test_native_pipeline_refuses_a_signal_file_that_is_not_numbers(tmp_path, built):
+    from chiron_amd import _lib
+    inp = tmp_path / "sig"
+    inp.mkdir()
+    (inp / "bad.signal").write_text("487 421 oops 433")
+    F = _flags(str(inp), str(tmp_path / "out"))
+    for sub in ("result", "segments", "meta"):
+        os.makedirs(os.path.join(F.output, sub))
+    with pytest.raises(_lib.ChironError) as err:
+        ce.evaluation(F, engine=CannedEngine(F.batch_size, F.segment_len))
+    assert "bad.signal" in str(err.value)
 
 
 def test_native_pipeline_reports_a_failed_write(tmp_path, built):
