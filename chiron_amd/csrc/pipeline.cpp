@@ -15,8 +15,9 @@
 //                    + meta/<name>.meta (:229-242)
 //
 // Same files as the Python pipeline, byte for byte (tests/test_gpu_parity.py, tests/test_pipeline_native.py), except the per-read
-// timings inside meta/*.meta.  Scope: fast5 input, population BN (a partial last batch is submitted as it is: rows are independent
-// of their batch there), host vote for every read.  Everything else stays with eval.evaluation.
+// timings inside meta/*.meta.  Scope: fast5 input or `.signal` text files (read_signal, chiron_input.py:527-539: nothing is written to raw/
+// then, names keep their sub-folder), population BN (a partial last batch is submitted as it is: rows are independent of their batch
+// there), host vote for every read.  Everything else stays with eval.evaluation.
 #include <atomic>
 #include <chrono>
 #include <cmath>
