@@ -538,9 +538,48 @@ def native_pipeline_ok(FLAGS, engine, fast5_files, signal_names=None):
     return isinstance(engine, Engine) and engine.spec.bn_mode == "population"
 
 
+class NativeResults(dict):
+    """What evaluation() returns after a native run: read name (+ ".signal", the Python pipeline's keys) -> consensus string, like the
+    dict the Python pipeline builds -- but the strings stay in result/<name>.<ext> until somebody asks for one (a sharded `chiron call`
+    never does: 10 000 reads are 10 000 small files nobody needs to read back)."""
+
+    def __init__(self, names, result_dir, ext, rna):
+        dict.__init__(self, ((n + ".signal", None) for n in names))
+        self._dir, self._ext, self._rna = result_dir, ext, rna
+
+    def _load(self, key):
+        text = open(os.path.join(self._dir, key[:-len(".signal")] + self._ext)).read().split("\n")
+        seq = text[1] if len(text) > 1 else ""
+        return seq.replace("U", "T").replace("u", "t") if self._rna else seq      # the returned string is the consensus before T -> U (finish_read)
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is None:
+            v = self._load(key)
+            dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def __eq__(self, other):
+        return dict(self.items()) == (dict(other.items()) if isinstance(other, dict) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+
 def run_native_pipeline(FLAGS, engine, fast5_files, n_threads, name_root=None):
-    """chiron_pipeline_run behind evaluation(): -> {read name + ".signal": None} (the consensus strings stay in result/; callers of
-    evaluation() use the keys).  Skipped files are logged the way extract.extract_records logs them."""
+    """chiron_pipeline_run behind evaluation(): -> NativeResults (read name + ".signal" -> consensus string, read from result/ on
+    demand).  Skipped files are logged the way extract.extract_records logs them."""
     import ctypes as C
     from . import _lib
     from . import extract as extract_mod
@@ -561,7 +600,7 @@ def run_native_pipeline(FLAGS, engine, fast5_files, n_threads, name_root=None):
     res_dir, ext = os.path.join(FLAGS.output, "result"), "." + FLAGS.extension
     names = sorted(os.path.relpath(os.path.join(dp, n), res_dir)[:-len(ext)] for dp, _, fns in os.walk(res_dir) for n in fns if n.endswith(ext))
     evaluation.last_native_stats = {k: getattr(stats, k) for k in ("reads", "reads_finished", "windows", "batches", "consensus_bases", "files_failed", "seconds")}
-    return {n + ".signal": None for n in names}
+    return NativeResults(names, res_dir, ext, getattr(FLAGS, "mode", "dna") == "rna")
 
 
 def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):

@@ -108,6 +108,7 @@ def test_native_pipeline_equals_the_python_pipeline_behind_a_null_engine(tmp_pat
         results[which] = ce.evaluation(F, engine=eng, fast5_files=files)
         trees[which] = _tree(out)
     assert sorted(results["python"]) == sorted(results["native"]) and len(results["native"]) == 12      # the damaged file is skipped by both
+    assert results["native"] == results["python"] and all(isinstance(v, str) for v in results["native"].values())   # name -> consensus string, read back on demand
     assert sorted(trees["python"]) == sorted(trees["native"])
     for name in trees["python"]:
         assert trees["python"][name] == trees["native"][name], name
