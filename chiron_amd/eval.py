@@ -650,6 +650,12 @@ def evaluation(FLAGS, engine=None, file_list=None, fast5_files=None):
     signal_names = None if fast5_files is not None else [n for n in files if n.endswith(".signal") or n.endswith(".fast5")]
     if native_pipeline_ok(FLAGS, engine, fast5_files, signal_names):
         # the whole host side in one native call: C++ reader / finisher threads, this thread packs and talks to the engine (csrc/pipeline.cpp)
+        if int(getattr(FLAGS, "threads", 0) or 0) <= 0:
+            # -t 0: C++ threads scale with their number on a rank of its own (2 / 3 / 6 / 12 reader + finisher threads: 0.61 / 0.92 / 1.80 /
+            # 3.35 M windows/s behind the null engine) -- and EIGHT ranks writing three files + 0.4 MB of raw/ text per read into one file
+            # system are fastest with few (1 / 2 / 3 / 4 / 6 / 10 per rank: 2.47 / 4.31 / 4.40 / 3.77 / 3.53 / 3.24 M in total): about 24
+            # reader threads per host (profiles/r06_host_ceiling.json)
+            n_threads = max(2, min(12, 24 // ranks_here, max(2, (os.cpu_count() or 8) // 2)))
         try:
             if fast5_files is not None:
                 return run_native_pipeline(FLAGS, engine, list(fast5_files), n_threads)
