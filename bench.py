@@ -368,7 +368,11 @@ def main():
                     "mfma_kernels": per_bucket,
                     "traffic_source": traffic_src,
                     "traffic_live": None if not live else {"error": live.get("error"), "seconds": live.get("seconds"),
-                                                            "hbm_bytes_per_launch": {k: v.get("hbm_bytes") for k, v in (live.get("kernels") or {}).items()}}}
+                                                            "hbm_bytes_per_launch": {k: v.get("hbm_bytes") for k, v in (live.get("kernels") or {}).items()},
+                                                            # the matrix pipe in THIS run (same child passes, SQ counters): busy share of the CUs a kernel
+                                                            # holds / of the whole chip, VALU share next to it (committed record: roofline.pmc)
+                                                            "mfma_busy": {k: {f: v[f] for f in ("mfma_busy_frac", "mfma_busy_frac_of_busy_cus", "valu_busy_frac_of_busy_cus") if f in v}
+                                                                          for k, v in (live.get("kernels") or {}).items() if "mfma_busy_frac_of_busy_cus" in v}}}
         # north_star: "rocprof HBM GB/s on the conv and MFMA utilisation on the LSTM": the PMC pass's counters next to this
         # run's launch times (HBM GB/s = PMC bytes per launch / HIP-event launch time); absent when the PMC record is stale
         for k in mfma_buckets:
@@ -734,20 +738,34 @@ def live_pmc_traffic():
         return {"error": "rocprofv3 not found"}
     acc = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        # two traffic passes, then the matrix-pipe pass (north_star: "MFMA utilisation on the LSTM"): the counters of tools/pmc_pass.sh
+        for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE"), ("SQ_ACTIVE_INST_VALU",)):
+            counter = " ".join(group)
             d = tempfile.mkdtemp(prefix="chiron_pmc_", dir="/tmp")
             try:
-                cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+                cmd = [exe, "--kernel-trace", "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=240)
                 files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
                 if r.returncode != 0 or not files:
-                    return {"error": "rocprofv3 --pmc %s: rc %d, %d csv files: %s" % (counter, r.returncode, len(files), (r.stderr or "")[-300:]), "seconds": round(time.perf_counter() - t0, 1)}
-                collect_counter(files, counter, acc)
+                    if group[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                        return {"error": "rocprofv3 --pmc %s: rc %d, %d csv files: %s" % (counter, r.returncode, len(files), (r.stderr or "")[-300:]), "seconds": round(time.perf_counter() - t0, 1)}
+                    break                                   # the traffic is in; the matrix-pipe figures stay with the committed record
+                for c in group:
+                    collect_counter(files, c, acc)
             finally:
                 shutil.rmtree(d, ignore_errors=True)
     except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
         return {"error": "%s: %s" % (type(e).__name__, e), "seconds": round(time.perf_counter() - t0, 1)}
     kernels = hbm_bytes_per_launch(acc)
+    for name, c in acc.items():                            # tools/pmc_to_json.py's formulas (mean per launch)
+        m = {k: sum(v) / len(v) for k, v in c.items()}
+        if name in kernels and m.get("SQ_BUSY_CU_CYCLES", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+            simd = 4.0 * m["SQ_BUSY_CU_CYCLES"]
+            kernels[name]["mfma_busy_frac_of_busy_cus"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / simd, 4)
+            if m.get("GRBM_GUI_ACTIVE", 0) > 0:
+                kernels[name]["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+            if "SQ_ACTIVE_INST_VALU" in m:
+                kernels[name]["valu_busy_frac_of_busy_cus"] = round(max(0.0, 4.0 * m["SQ_ACTIVE_INST_VALU"] - m.get("SQ_INSTS_MFMA", 0.0)) / simd, 4)
     return {"kernels": kernels, "seconds": round(time.perf_counter() - t0, 1), "error": None if kernels else "no kernel carried both counters"}
 
 
