@@ -339,8 +339,9 @@ def main():
             if rec and rec.get("hbm_bytes"):
                 static_traffic, static_src = traffic, traffic_src
                 traffic = rec["hbm_bytes"]
-                traffic_src = ("measured in THIS run: two child processes of this script under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
-                               "(separate passes, %d / %d launches, three single-slot batches each); committed record for comparison: %s (%s)"
+                traffic_src = ("measured in THIS run: child processes of this script under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
+                               "(separate passes, %d / %d launches, three single-slot batches each; two more passes take the SQ counters of "
+                               "traffic_live.mfma_busy); committed record for comparison: %s (%s)"
                                % (rec["launches_fetch"], rec["launches_write"], static_traffic, static_src))
         per_bucket = {k: {"symbol": BUCKET_SYMBOL[k], "ms_per_batch": round(stats[k]["total_ms"] / 3.0, 4),
                           "launches_per_batch": stats[k]["launches"] / 3.0,
