@@ -745,7 +745,7 @@ def live_pmc_traffic():
             d = tempfile.mkdtemp(prefix="chiron_pmc_", dir="/tmp")
             try:
                 cmd = [exe, "--kernel-trace", "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=240)
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=60)   # a pass takes about a second; a profiler that hangs must not hold the bench
                 files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
                 if r.returncode != 0 or not files:
                     if group[0] in ("FETCH_SIZE", "WRITE_SIZE"):
