@@ -529,7 +529,12 @@ static chiron_status build_plans(chiron_engine* e, const float* w) {
       // products per output pair instead of six.  U_j[n][c] in float64 from the folded taps g_tap = W2b[tap][c][n]*inv[n].
       if (!bp.lift && !batch && !e->f16 && !e->split && b.k == 3 && b.stride == 1 && (t % 2) == 0 && co % 64 == 0 && ci == co &&
           getenv("CHIRON_NO_WINOGRAD") == nullptr) {
-        const bool f4 = (t % 4) == 0 && getenv("CHIRON_WINOGRAD_F2") == nullptr;
+        // F(4,3) from 256 frames per window on (round 6): its rounding error is correlated over the four frames of a quad and, measured
+        // against the float32 ensembles of tests/golden/parity_dist, costs the short strided topology more than it saves -- RNA_default
+        // (T = 100): typical window 1.32 .. 1.45 -> 1.13 .. 1.20 x the ensemble's median, tail 7 .. 9 % -> 2 .. 5 % with F(2,3), for 0.04 ms
+        // of its 1.7 ms batch; DNA_default (T = 400): parity within the noise of F(2,3)'s, F(4,3) worth 4.1 % of the headline.
+        // CHIRON_WINOGRAD_F4=1 / CHIRON_WINOGRAD_F2=1 force either form.
+        const bool f4 = (t % 4) == 0 && getenv("CHIRON_WINOGRAD_F2") == nullptr && (t >= 256 || getenv("CHIRON_WINOGRAD_F4") != nullptr);
         const int nu = f4 ? 6 : 4;
         // F(4,3): U = G g;  F(2,3): g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2
         static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
