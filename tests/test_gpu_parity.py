@@ -492,39 +492,40 @@ def test_wide_recurrence_agrees_with_the_narrow_form_and_is_repack_stable(dna, r
 
 
 def test_winograd_conv2b_against_direct_form_and_oracle(dna, rna, monkeypatch):
-    """wino.hip: conv2b of the blocks after the first one in Winograd form -- F(4,3) when the length is a multiple of 4
-    (6 products per 4 outputs instead of 12), F(2,3) when it is only even (4 per 2 instead of 6; also forced with
-    CHIRON_WINOGRAD_F2=1), the direct form otherwise (CHIRON_NO_WINOGRAD=1 forces it).  Same function re-associated:
-    logits within 3e-5 of the direct-form engine and within the 1e-4 bound of the float64 oracle; segment boundaries
-    inside a tile (SAME padding zeros at both ends of every segment), ragged and empty rows, a batch that does not fill
-    the last tile, and the RNA graph (T = 100).  An odd length runs the direct form: identical bits with and without
-    the switches."""
+    """wino.hip: conv2b of the blocks after the first one in Winograd form -- F(4,3) when the window holds at least 256 frames and their
+    number is a multiple of 4 (6 products per 4 outputs instead of 12; CHIRON_WINOGRAD_F4=1 takes it for any multiple of 4), F(2,3)
+    when the length is only even or the window is short (4 per 2 instead of 6; RNA_default's 100 frames since round 6 -- the parity
+    trade-off of DESIGN 3.1b / 4; forced with CHIRON_WINOGRAD_F2=1), the direct form otherwise (CHIRON_NO_WINOGRAD=1 forces it).  Same
+    function re-associated: logits within 3e-5 of the direct-form engine and within the 1e-4 bound of the float64 oracle; segment
+    boundaries inside a tile (SAME padding zeros at both ends of every segment), ragged and empty rows, a batch that does not fill
+    the last tile, and the RNA graph (T = 100) in BOTH Winograd forms.  An odd length runs the direct form: identical bits with and
+    without the switches."""
     from oracle import nn_oracle
-    for (spec, w), L, B, form in ((dna, 400, 37, "f4"), (dna, 64, 5, "f4"), (rna, 500, 21, "f4"), (dna, 398, 9, "f2"), (dna, 399, 6, "direct")):
+    switches = ("CHIRON_WINOGRAD_F2", "CHIRON_WINOGRAD_F4", "CHIRON_NO_WINOGRAD")
+    for (spec, w), L, B, default_form, f4_possible in ((dna, 400, 37, "f4", True), (dna, 64, 5, "f2", True), (rna, 500, 21, "f2", True),
+                                                       (dna, 398, 9, "f2", False), (dna, 399, 6, "direct", False)):
         x, ln = _windows(L * B, L, L, seed=77 + L)
         x, ln = x[:B], ln[:B].copy()
         ln[1] = 0
         ln[B - 1] = L // 3
         outs = {}
-        for mode, env in (("default", None), ("f2", "CHIRON_WINOGRAD_F2"), ("direct", "CHIRON_NO_WINOGRAD")):
-            for v in ("CHIRON_WINOGRAD_F2", "CHIRON_NO_WINOGRAD"):
+        for mode, env in (("default", None), ("f2", "CHIRON_WINOGRAD_F2"), ("f4", "CHIRON_WINOGRAD_F4"), ("direct", "CHIRON_NO_WINOGRAD")):
+            for v in switches:
                 monkeypatch.delenv(v, raising=False)
             if env:
                 monkeypatch.setenv(env, "1")
             with ca.Engine(spec, w, max_batch=B, segment_len=L) as eng:
                 sl = ca.seq_len_for_engine(ln, eng.ratio)
                 outs[mode] = eng.infer(x, sl, want_logits=True).logits.copy()
-        for v in ("CHIRON_WINOGRAD_F2", "CHIRON_NO_WINOGRAD"):
+        for v in switches:
             monkeypatch.delenv(v, raising=False)
-        if form == "direct":
-            assert np.array_equal(outs["default"], outs["direct"]) and np.array_equal(outs["f2"], outs["direct"])
+        if default_form == "direct":
+            assert all(np.array_equal(outs[m], outs["direct"]) for m in outs)
         else:
-            assert 0 < np.abs(outs["default"] - outs["direct"]).max() < 3e-5
             assert 0 < np.abs(outs["f2"] - outs["direct"]).max() < 3e-5
-            if form == "f4":
-                assert not np.array_equal(outs["default"], outs["f2"])       # the default really took the F(4,3) kernel
-            else:
-                assert np.array_equal(outs["default"], outs["f2"])
+            assert 0 < np.abs(outs["f4"] - outs["direct"]).max() < 3e-5
+            assert np.array_equal(outs["default"], outs[default_form])                        # which kernel the default took
+            assert np.array_equal(outs["f4"], outs["f2"]) == (not f4_possible)                # F(4,3) is a different kernel wherever the length allows it
         ref, _ = nn_oracle.inference(x, sl, spec.to_dict(), w, dtype=np.float64)
         for mode in outs:
             assert np.abs(outs[mode] - ref).max() < TOL, mode
@@ -542,7 +543,7 @@ def _engine_variants(monkeypatch):
 
 
 _REGIME_ENV = ("CHIRON_LSTM_PAIR", "CHIRON_LSTM_WIDE", "CHIRON_LSTM16_FUSED_MIN", "CHIRON_LSTM16_UNFUSED", "CHIRON_LSTM16_NARROW", "CHIRON_NO_WINOGRAD",
-               "CHIRON_WINOGRAD_F2")
+               "CHIRON_WINOGRAD_F2", "CHIRON_WINOGRAD_F4")
 
 
 def _run_variant(monkeypatch, spec, w, x, ln, L, dtype, env, features=False):
@@ -640,7 +641,7 @@ def test_trained_like_weights_through_every_conv_form(dna, rna, monkeypatch, cas
     report["feature_rms"] = float(np.sqrt((fea64 ** 2).mean()))
     report["features/numpy-fp32"] = float(np.abs(fea32 - fea64).max())
     errs, failures = {}, []
-    for form, env in (("default", {}), ("f2", {"CHIRON_WINOGRAD_F2": "1"}), ("direct", {"CHIRON_NO_WINOGRAD": "1"})):
+    for form, env in (("default", {}), ("f2", {"CHIRON_WINOGRAD_F2": "1"}), ("f4", {"CHIRON_WINOGRAD_F4": "1"}), ("direct", {"CHIRON_NO_WINOGRAD": "1"})):
         got, sl, fea = _run_variant(monkeypatch, spec, w, x, ln, L, "fp32", env, features=True)
         errs[form] = float(np.abs(fea - fea64).max())
         report["features/" + form] = errs[form]
