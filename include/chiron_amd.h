@@ -107,7 +107,7 @@ chiron_status chiron_weights_size(const chiron_model_desc* desc, size_t* n_float
  *             and CTC are the fp32 code.  Opt-in.  What it meets (tests): the 1e-4 logits bound against the oracle on the seeded
  *             synthetic weights, as CHIRON_F32 does; on trained-checkpoint-like weights, where no float32 pipeline meets 1e-4, it is
  *             judged against the same ensemble of float32 realisations as CHIRON_F32 with wider bars (bulk rms <= 1.5 x the ensemble's
- *             p90, typical window <= 1.75 x its median; measured 0.75 .. 1.4 and 1.0 .. 1.6 -- CHIRON_F32: 0.65 .. 1.15 and 1.2 .. 1.45);
+ *             p90, typical window <= 1.75 x its median; measured 0.75 .. 1.4 and 1.0 .. 1.6 -- CHIRON_F32: 0.63 .. 1.15 and 1.13 .. 1.23);
  *             greedy strings at basecalling density as CHIRON_F32.  It is not fp32 MFMA arithmetic, so the headline benchmark stays
  *             on CHIRON_F32.  Population BN only.
  * CHIRON_F16_W2: CHIRON_F16's activations (halves) against EXACT weights: every weight is carried as a hi + lo half pair
