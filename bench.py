@@ -107,7 +107,8 @@ def main():
                          "its initialisation raises, the ranks fall back to gloo together and config.parallelism_bookkeeping says so")
     ap.add_argument("--share-gpu", action="store_true", help="self-test only: every rank uses GPU 0")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic in THIS run")
-    ap.add_argument("--pmc-child", action="store_true", help="internal: three single-slot batches and exit (the workload of the --pmc child runs)")
+    ap.add_argument("--pmc-child", nargs="?", const="fp32", default=None, metavar="DTYPE",
+                    help="internal: three single-slot batches of the headline workload in DTYPE (fp32 / fp32-split) and exit (the workload of the --pmc child runs)")
     ap.add_argument("--no-f16", action="store_true", help="skip the extra measurements (configs[4]: fp16 batch 4096; fp32-split dtype)")
     ap.add_argument("--stub-engine", type=float, default=0.0, metavar="MS",
                     help="self-test of the multi-rank bookkeeping WITHOUT a GPU (tests/test_bench_ranks.py): the engine is replaced "
@@ -116,7 +117,7 @@ def main():
                          "line says data = 'stub'.")
     args = ap.parse_args()
     if args.pmc_child:
-        return pmc_child()
+        return pmc_child(args.pmc_child)
     stub = args.stub_engine > 0
     if stub:
         args.no_f16, args.no_cpu_baseline, args.density_rounds = True, True, 0
@@ -422,7 +423,7 @@ def main():
     if ref32 is not None:
         out["extra"]["config5_f16"] = f16_config(spec, weights, x_dev, s_dev, ref32, local_rank)
         out["extra"]["config5_f16_w2"] = f16_config(spec, weights, x_dev, s_dev, ref32, local_rank, dtype="fp16-w2")
-        out["extra"]["f32_split_dtype"] = split_config(spec, weights, x_dev, s_dev, ref32, local_rank)
+        out["extra"]["f32_split_dtype"] = split_config(spec, weights, x_dev, s_dev, ref32, local_rank, live_pmc=not args.no_live_pmc)
         # BASELINE configs[4]'s tolerance check where it means something (round-5 review, item 3): windows whose greedy string equals the fp32
         # engine's, next to the flat-weights logits_vs_f32 above -- measured in this run at a trained model's decode density, and the
         # committed frontier of every half-precision mode in three regimes (tools/f16_frontier.py)
@@ -631,7 +632,7 @@ def f16_config(spec, weights, x_dev, s_dev, ref32, device_id, dtype="fp16"):
             "logits_vs_f32": {"max_abs": round(float(d.max()), 5), "mean_abs": round(float(d.mean()), 6), "windows": BATCH}}
 
 
-def split_config(spec, weights, x_dev, s_dev, ref32, device_id):
+def split_config(spec, weights, x_dev, s_dev, ref32, device_id, live_pmc=True):
     """Opt-in dtype fp32-split on the headline workload (same batch 1100, three slots): fp32 values carried as hi + lo
     half pairs, GEMMs on the f16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate), everything else the fp32 code.
     Reported next to the headline, never as `value`; with its logits deviation from the fp32 engine."""
@@ -679,7 +680,17 @@ def split_config(spec, weights, x_dev, s_dev, ref32, device_id):
                 "executed_flops": "3 x the algorithmic FLOPs (three f16 MFMA terms per fp32 product); algorithmic_tflops / 157.3 is the figure comparable with the fp32 engine's roofline",
                 "frac_of_fp32_mfma_peak_in_algorithmic_flops": round(kern[dom]["algorithmic_tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                 "mfma_kernels": kern, "single_slot_ms_per_batch": round(tot_ms, 3),
-                "traffic": None, "traffic_note": "no PMC pass for this dtype; profiles/r06_split_kernel_stats.csv holds the rocprofv3 kernel table"}
+                "traffic": None, "traffic_note": "no PMC pass for this dtype in this run; profiles/r06_split_kernel_stats_slots1.csv holds the rocprofv3 kernel table"}
+    if live_pmc:       # the same two traffic passes as the headline's, over this dtype's engine (its recurrence: lstm32s_kernel)
+        live = live_pmc_traffic("fp32-split", traffic_only=True)
+        rec = next((v for k, v in (live.get("kernels") or {}).items() if k.startswith("lstm32s_kernel")), None) if dom == "lstm_recurrence" else None
+        roofline["traffic_live"] = {"error": live.get("error"), "seconds": live.get("seconds"),
+                                    "hbm_bytes_per_launch": {k: v["hbm_bytes"] for k, v in (live.get("kernels") or {}).items()}}
+        if rec and rec.get("hbm_bytes"):
+            roofline["traffic"] = rec["hbm_bytes"]
+            roofline["algorithmic_bytes_per_launch"] = stats[dom]["bytes"] / stats[dom]["launches"]
+            roofline["traffic_note"] = ("HBM bytes per launch of lstm32s_kernel measured in THIS run: child processes under rocprofv3 --kernel-trace --pmc "
+                                        "FETCH_SIZE / WRITE_SIZE (separate passes, %d / %d launches), (2*FETCH_SIZE + WRITE_SIZE)*1024" % (rec["launches_fetch"], rec["launches_write"]))
     return {"workload": "headline workload (batch 1100, greedy), dtype fp32-split",
             "kbases_per_s": round(steps * BATCH * BASES_PER_WINDOW / 1000.0 / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3),
             "roofline": roofline,
@@ -687,13 +698,13 @@ def split_config(spec, weights, x_dev, s_dev, ref32, device_id):
                                      "greedy_decode_identical": bool(same), "windows": BATCH}}
 
 
-def pmc_child():
-    """--pmc-child: the workload of the live PMC passes -- the headline engine, ONE slot, three batches of the headline workload from host
-    buffers, no timing, no torch.  rocprofv3 wraps this process; the parent parses its counter_collection.csv."""
+def pmc_child(dtype="fp32"):
+    """--pmc-child [DTYPE]: the workload of the live PMC passes -- the headline engine (or its fp32-split form), ONE slot, three batches of the
+    headline workload from host buffers, no timing, no torch.  rocprofv3 wraps this process; the parent parses its counter_collection.csv."""
     import chiron_amd as ca
     spec = ca.dna_default_spec()
     xb, lb, _, _ = make_batches(1, 0)
-    with ca.Engine(spec, ca.synthetic_weights(spec, seed=1234), max_batch=BATCH, segment_len=SEG_LEN, n_slots=1) as eng:
+    with ca.Engine(spec, ca.synthetic_weights(spec, seed=1234), max_batch=BATCH, segment_len=SEG_LEN, n_slots=1, dtype=dtype) as eng:
         sl = ca.seq_len_for_engine(lb[0], eng.ratio)
         for _ in range(3):
             eng.submit(0, xb[0], sl, beam_width=0, want_prob=True)
@@ -723,7 +734,7 @@ def hbm_bytes_per_launch(acc):
     return kernels
 
 
-def live_pmc_traffic():
+def live_pmc_traffic(dtype="fp32", traffic_only=False):
     """HBM bytes per launch of every kernel of the path, measured in THIS run (round-5 review, Weak #6: the line used to carry the
     builder's committed record): this script as a child process under `rocprofv3 --kernel-trace --pmc <counter>`, once for FETCH_SIZE
     and once for WRITE_SIZE (separate passes, kernel trace only -- MI355X_MICROARCH.md's recipe), from /tmp.  hbm_bytes =
@@ -740,11 +751,12 @@ def live_pmc_traffic():
     acc = {}
     try:
         # two traffic passes, then the matrix-pipe pass (north_star: "MFMA utilisation on the LSTM"): the counters of tools/pmc_pass.sh
-        for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE"), ("SQ_ACTIVE_INST_VALU",)):
+        groups = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE"), ("SQ_ACTIVE_INST_VALU",))
+        for group in groups[:2] if traffic_only else groups:
             counter = " ".join(group)
             d = tempfile.mkdtemp(prefix="chiron_pmc_", dir="/tmp")
             try:
-                cmd = [exe, "--kernel-trace", "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+                cmd = [exe, "--kernel-trace", "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", dtype]
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=60)   # a pass takes about a second; a profiler that hangs must not hold the bench
                 files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
                 if r.returncode != 0 or not files:
